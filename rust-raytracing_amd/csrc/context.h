@@ -1,0 +1,100 @@
+// Shared between the translation units of librtamd.so: the context object, error plumbing and the
+// per-precision entry points.  The f32 and f64 kernels live in separate translation units (rt_f32.hip,
+// rt_f64.hip) so that the f64 build can be compiled without multiply-add contraction: its results then
+// track a plain IEEE f64 evaluation (what the Rust reference does) operation for operation.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "device_scene.h"
+#include "rtamd.h"
+
+namespace rti {
+using namespace rtd;
+
+extern thread_local std::string g_err;
+inline int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                                  \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return ::rti::fail(RT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+constexpr uint32_t kBlock = 256;
+constexpr uint32_t kLdsAllMax = 64u * 1024u;  // stage the whole scene in LDS up to this size
+constexpr uint32_t kLdsTopMax = 32u * 1024u;  // otherwise stage this many bytes of top-level BVH links
+constexpr uint64_t kTargetPathsPerPass = 16ull << 20;
+constexpr uint32_t kMaxDepth = 4096;
+constexpr uint32_t kCounterWords = (kMaxDepth + 2) + (kMaxDepth + 2) * 8;  // queue counts + per-bounce class counts
+
+template <class R> struct SceneImage {
+  uint8_t* d_blob = nullptr;
+  DeviceScene<R> dev{};
+  bool lds_all = false;
+  uint32_t lds_bytes = 0;
+};
+
+struct TmpLink {
+  double bmin[3], bmax[3];
+  uint32_t hit;
+  int32_t miss;
+  int32_t depth, tree;
+};
+
+inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
+
+}  // namespace rti
+
+struct rt_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int n_cus = 256;
+  bool has_scene = false;
+  rti::SceneImage<float> sf;
+  rti::SceneImage<double> sd;
+  rtd::DImage* d_images = nullptr;
+  std::vector<uint8_t*> d_image_bytes;
+  // render workspace
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  uint32_t* d_counters = nullptr;  // [kCounterWords]
+  unsigned long long* d_ray_count = nullptr;
+  void* accum = nullptr;
+  size_t accum_bytes = 0;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+namespace rti {
+
+template <class R> SceneImage<R>& image_of(rt_context* c);
+template <> inline SceneImage<float>& image_of<float>(rt_context* c) { return c->sf; }
+template <> inline SceneImage<double>& image_of<double>(rt_context* c) { return c->sd; }
+
+inline uint32_t grid_for(const rt_context* c, uint64_t n, uint32_t blocks_per_cu) {
+  uint64_t want = (n + kBlock - 1) / kBlock;
+  uint64_t cap = (uint64_t)c->n_cus * blocks_per_cu;
+  return (uint32_t)std::max<uint64_t>(1, std::min(want, cap));
+}
+
+// Implemented once per precision (rt_f32.hip / rt_f64.hip).
+template <class R>
+int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink>& links, int root_link, const std::vector<int>& sub_root_of_object,
+                SceneImage<R>& im);
+template <class R> int render_accum_impl(rt_context* c, const rt_render_params& p, void* accum_dev, rt_stats* stats);
+template <class R> int trace_batch_impl(rt_context* c, const rt_ray* rays, size_t n, rt_hit* hits, uint64_t seed);
+template <class R>
+int pairs_kernel_impl(rt_context* c, int which, uint32_t W, uint32_t H, uint32_t max_depth, const uint32_t* pixel, const uint32_t* sample, size_t n,
+                      uint64_t seed, void* out, size_t out_bytes);
+template <class R> int resolve_impl(rt_context* c, const void* accum_dev, size_t n_pixels, uint32_t spp, uint8_t* d_rgb);
+
+}  // namespace rti

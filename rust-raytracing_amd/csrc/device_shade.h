@@ -1,0 +1,177 @@
+// Shading for one hit per lane: Material::emitted / Material::scatter (src/material.rs), Texture::value
+// (src/texture.rs), Perlin noise (src/perlin.rs), the miss shader (src/color.rs:41-51), primary-ray
+// generation (src/render.rs:230-234 + src/camera.rs:62-72) and the final colour conversion (src/color.rs:14-27).
+#pragma once
+#include "device_trace.h"
+
+namespace rtd {
+
+template <class R> RT_DEV R perlin_noise(const DPerlin<R>& pn, V3<R> pt) {  // src/perlin.rs:32-55,116-139
+  R fx = rt_floor(pt.x), fy = rt_floor(pt.y), fz = rt_floor(pt.z);
+  R u = pt.x - fx, v = pt.y - fy, w = pt.z - fz;
+  int i = (int)fx, j = (int)fy, k = (int)fz;
+  R uu = u * u * ((R)3 - (R)2 * u);
+  R vv = v * v * ((R)3 - (R)2 * v);
+  R ww = w * w * ((R)3 - (R)2 * w);
+  R accum = 0;
+#pragma unroll
+  for (int di = 0; di < 2; ++di)
+#pragma unroll
+    for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+      for (int dk = 0; dk < 2; ++dk) {
+        int idx = pn.perm[0][(i + di) & 255] ^ pn.perm[1][(j + dj) & 255] ^ pn.perm[2][(k + dk) & 255];
+        V3<R> c(pn.ran[idx][0], pn.ran[idx][1], pn.ran[idx][2]);
+        R fi = (R)di, fj = (R)dj, fk = (R)dk;
+        V3<R> weight_v(u - fi, v - fj, w - fk);
+        accum += (fi * uu + ((R)1 - fi) * ((R)1 - uu)) * (fj * vv + ((R)1 - fj) * ((R)1 - vv)) *
+                 (fk * ww + ((R)1 - fk) * ((R)1 - ww)) * dot(c, weight_v);
+      }
+  return accum;
+}
+
+template <class R> RT_DEV R perlin_turbulence(const DPerlin<R>& pn, V3<R> pt, int depth) {  // src/perlin.rs:60-72
+  R accum = 0;
+  V3<R> temp_p = pt;
+  R weight = 1;
+  for (int i = 0; i < depth; ++i) {
+    accum += weight * perlin_noise(pn, temp_p);
+    weight *= (R)0.5;
+    temp_p = (R)2 * temp_p;
+  }
+  return rt_abs(accum);
+}
+
+RT_DEV uint32_t sat_u32(float x) { return !(x > 0.0f) ? 0u : (x >= 4294967295.0f ? 4294967295u : (uint32_t)x); }
+RT_DEV uint32_t sat_u32(double x) { return !(x > 0.0) ? 0u : (x >= 4294967295.0 ? 4294967295u : (uint32_t)x); }
+
+// Texture::value.  LEVEL 0 may be a checker whose two sub-textures are evaluated at LEVEL 1.
+template <class R, bool L, int LEVEL> RT_DEV V3<R> texture_value(const SceneView<R, L>& sv, int tex, R u, R v, V3<R> p) {
+  const DTexture<R> t = sv.textures[tex];
+  switch (t.tag) {
+    case TEX_SOLID: return V3<R>(t.color[0], t.color[1], t.color[2]);  // src/texture.rs:29-33
+    case TEX_CHECKER: {                                               // src/texture.rs:54-63
+      if constexpr (LEVEL == 0) {
+        R sines = rt_sin((R)10 * p.x) * rt_sin((R)10 * p.y) * rt_sin((R)10 * p.z);
+        return texture_value<R, L, 1>(sv, sines < (R)0 ? t.odd : t.even, u, v, p);
+      } else {
+        return V3<R>((R)0, (R)0, (R)0);
+      }
+    }
+    case TEX_NOISE: {  // src/texture.rs:79-85
+      R s = (R)1 + rt_sin(t.scale * p.z + (R)10 * perlin_turbulence(sv.perlins[t.perlin], p, 7));
+      return (V3<R>((R)1, (R)1, (R)1) * V3<R>((R)0.5, (R)0.5, (R)0.5)) * V3<R>(s, s, s);
+    }
+    case TEX_IMAGE: {  // src/texture.rs:128-159
+      if (t.image < 0) return V3<R>((R)0, (R)1, (R)1);
+      const DImage im = sv.images[t.image];
+      R uc = rt_min(rt_max(u, (R)0), (R)1);
+      R vc = (R)1 - rt_min(rt_max(v, (R)0), (R)1);
+      uint32_t i = sat_u32(uc * (R)im.width);
+      uint32_t j = sat_u32(vc * (R)im.height);
+      if (i >= (uint32_t)im.width) i = (uint32_t)im.width - 1u;
+      if (j >= (uint32_t)im.height) j = (uint32_t)im.height - 1u;
+      const uint8_t* px = im.rgb + ((size_t)j * (size_t)im.width + i) * 3u;
+      R color_scale = (R)1 / (R)255;
+      return V3<R>(color_scale * (R)px[0], color_scale * (R)px[1], color_scale * (R)px[2]);
+    }
+    default: return V3<R>((R)0, (R)0, (R)0);
+  }
+}
+
+template <class R> RT_DEV R schlick_reflectance(R cosine, R ref_idx) {  // src/material.rs:104-109, powi(5) = x * (x^2)^2
+  R r0 = ((R)1 - ref_idx) / ((R)1 + ref_idx);
+  r0 = r0 * r0;
+  R x = (R)1 - cosine;
+  R x2 = x * x;
+  R x4 = x2 * x2;
+  return r0 + ((R)1 - r0) * (x * x4);
+}
+
+// material.emitted + material.scatter for a final hit record (src/render.rs:162-176).
+// Returns true when a scattered ray exists; `emitted` is always written.
+template <class R, bool L>
+RT_DEV bool shade_hit(const SceneView<R, L>& sv, const Ray<R>& ray_in, Rec<R>& rec, Stream& rng, V3<R>& emitted, V3<R>& attenuation,
+                      Ray<R>& scattered) {
+  rec.finish_uv();
+  const DMaterial<R> m = sv.materials[rec.mat];
+  emitted = V3<R>((R)0, (R)0, (R)0);
+  scattered.o = rec.p;
+  scattered.time = ray_in.time;
+  switch (m.tag) {
+    case MAT_LAMBERTIAN: {  // src/material.rs:43-57
+      V3<R> dir = rec.n + random_unit_vector<R>(rng);
+      if (near_zero(dir)) dir = rec.n;
+      scattered.d = dir;
+      attenuation = texture_value<R, L, 0>(sv, m.texture, rec.u, rec.v, rec.p);
+      return true;
+    }
+    case MAT_METAL: {  // src/material.rs:75-90
+      V3<R> reflected = reflect(unit_vector(ray_in.d), rec.n);
+      scattered.d = reflected + m.fuzz * random_in_unit_sphere<R>(rng);
+      attenuation = V3<R>(m.albedo[0], m.albedo[1], m.albedo[2]);
+      return dot(scattered.d, rec.n) > (R)0;
+    }
+    case MAT_DIELECTRIC: {  // src/material.rs:113-139
+      attenuation = V3<R>((R)1, (R)1, (R)1);
+      R refraction_ratio = rec.front ? (R)1 / m.ir : m.ir;
+      V3<R> unit_direction = unit_vector(ray_in.d);
+      R cos_theta = rt_min(dot(-unit_direction, rec.n), (R)1);
+      R sin_theta = rt_sqrt((R)1 - cos_theta * cos_theta);
+      bool cannot_refract = refraction_ratio * sin_theta > (R)1;
+      bool do_reflect = cannot_refract;
+      if (!do_reflect) do_reflect = schlick_reflectance(cos_theta, refraction_ratio) > gen01<R>(rng);  // `||` short-circuit
+      scattered.d = do_reflect ? reflect(unit_direction, rec.n) : refract(unit_direction, rec.n, refraction_ratio);
+      return true;
+    }
+    case MAT_LIGHT: {  // src/material.rs:159-167
+      emitted = texture_value<R, L, 0>(sv, m.texture, rec.u, rec.v, rec.p);
+      return false;
+    }
+    case MAT_ISOTROPIC: {  // src/material.rs:186-195
+      scattered.d = random_in_unit_sphere<R>(rng);
+      attenuation = texture_value<R, L, 0>(sv, m.texture, rec.u, rec.v, rec.p);
+      return true;
+    }
+    default: return false;
+  }
+}
+
+template <class R> RT_DEV V3<R> background_color(const DBackground<R>& bg, V3<R> direction) {  // src/color.rs:42-50
+  if (bg.kind == 0) return bg.c0;
+  V3<R> ud = unit_vector(direction);
+  R t = (R)0.5 * (ud.y + (R)1);
+  return ((R)1 - t) * bg.c1 + t * bg.c0;
+}
+
+// Primary ray of (pixel, sample): src/render.rs:230-234 then Camera::get_ray (src/camera.rs:62-72).
+// pixel = y * W + x with y counted from the top row; the reference's j is H - 1 - y.
+template <class R>
+RT_DEV Ray<R> primary_ray(const DCamera<R>& cam, uint32_t W, uint32_t H, uint32_t pixel, uint32_t sample, uint64_t seed) {
+  uint32_t y = pixel / W, i = pixel - y * W, j = H - 1u - y;
+  Stream rng(seed, pixel, sample, 0u, STAGE_CAMERA);
+  R u_rand = gen01<R>(rng);
+  R v_rand = gen01<R>(rng);
+  R s = ((R)i + u_rand) / (R)(W - 1u);
+  R t = ((R)j + v_rand) / (R)(H - 1u);
+  V3<R> rd = cam.lens_radius * random_in_unit_disk<R>(rng);
+  V3<R> offset = (cam.u * V3<R>(rd.x, rd.x, rd.x)) + (cam.v * V3<R>(rd.y, rd.y, rd.y));
+  Ray<R> ray;
+  ray.d = cam.lower_left_corner + s * cam.horizontal + t * cam.vertical - cam.origin - offset;
+  ray.time = gen_range<R>(rng, cam.t_open, cam.t_close);
+  ray.o = cam.origin + offset;
+  return ray;
+}
+
+// color_to_rgb (src/color.rs:14-27); Rust `as u8` saturates and maps NaN to 0.
+template <class R> RT_DEV uint8_t to_u8(R sum, R scale) {
+  R x = rt_sqrt(scale * sum);
+  if (x < (R)0) x = (R)0;
+  if (x > (R)0.999) x = (R)0.999;
+  R y = (R)256 * x;
+  if (!(y > (R)0)) return 0;
+  if (y >= (R)255) return 255;
+  return (uint8_t)y;
+}
+
+}  // namespace rtd

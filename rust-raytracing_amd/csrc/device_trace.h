@@ -1,0 +1,323 @@
+// Closest-hit query: world.hit(ray, t_min, t_max, rec) of the reference, for one ray per lane.
+//   BVH descent        src/bvh.rs:108-119      -> traverse()
+//   Aabb::hit          src/aabb.rs:30-46       -> aabb_hit()
+//   Sphere             src/sphere.rs:38-73     MovingSphere  src/moving_sphere.rs:44-72
+//   XY/XZ/YZRect       src/aarect.rs:88-177    Box           src/box_struct.rs:86-94 + src/hittable_list.rs:29-43
+//   Translate/RotateY  src/hittable.rs:140-151,213-242
+//   ConstantMedium     src/constant_medium.rs:41-111
+#pragma once
+#include "device_scene.h"
+
+namespace rtd {
+
+template <class R> struct Ray {
+  V3<R> o, d;
+  R time;
+  RT_DEV V3<R> at(R t) const { return o + (t * d); }  // src/ray.rs:31-33
+};
+
+// HitRecord (src/hittable.rs:10-18).  `uv_lazy`: (u, v, uw) hold the unit outward normal of the last accepted
+// static sphere and get_sphere_uv (src/sphere.rs:24-34) is evaluated once, when the record is final, instead
+// of on every accepted candidate; a record written by a shape that leaves u, v untouched (moving sphere,
+// medium) keeps whatever was there, exactly as the reference's shared `rec` does.
+template <class R> struct Rec {
+  V3<R> p, n;
+  R t, u, v, uw;
+  int32_t front, mat, obj, sub, side, uv_lazy;
+  int32_t leaf;  // device index of the object whose surface was hit, -1 for a medium (see Origin)
+  RT_DEV Rec() : t(0), u(0), v(0), uw(0), front(0), mat(-1), obj(-1), sub(-1), side(-1), uv_lazy(0), leaf(-1) {}
+  RT_DEV void set_face_normal(V3<R> dir, V3<R> outward) {  // src/hittable.rs:79-86
+    front = dot(dir, outward) < (R)0;
+    n = front ? outward : -outward;
+  }
+  RT_DEV void finish_uv() {  // src/sphere.rs:24-34
+    if (uv_lazy) {
+      const R PI = (R)3.14159265358979323846264338327950288;
+      R theta = rt_acos(-v);
+      R phi = rt_atan2(-uw, u) + PI;
+      u = phi / ((R)2 * PI);
+      v = theta / PI;
+      uv_lazy = 0;
+    }
+  }
+};
+
+// Surface a ray starts on, packed as (leaf + 1) << 3 | (side + 1); 0 = none (camera rays, medium scatter, test rays).
+//
+// Single precision only.  The reference separates a scattered ray from its own surface with t_min = 0.001 measured in
+// units of |direction|; a Lambertian direction can be 1e-3 long, so the physical gap is as small as 1e-6, far below the
+// f32 rounding error of a hit point at coordinates of a few hundred (3e-5), and the ray would re-hit its own surface and
+// stay trapped behind it.  In exact arithmetic a ray leaving a plane meets that plane again only at t = 0 and a ray
+// leaving a sphere meets it at t = 0 and t = -2*half_b/a (the constant term of the quadratic is exactly 0); the f32
+// kernels use exactly those facts for the one primitive the ray starts on, which is what the f64 evaluation reproduces
+// to 1e-13.  The f64 kernels never look at the origin tag.
+struct Origin {
+  uint32_t bits;
+  RT_DEV Origin() : bits(0) {}
+  RT_DEV explicit Origin(uint32_t b) : bits(b) {}
+  RT_DEV Origin(int leaf, int side) : bits(leaf < 0 ? 0u : (((uint32_t)leaf + 1u) << 3) | (uint32_t)(side + 1)) {}
+  RT_DEV int leaf() const { return (int)(bits >> 3) - 1; }
+  RT_DEV int side() const { return (int)(bits & 7u) - 1; }
+};
+template <class R> struct Guard { static constexpr bool on = false; };
+template <> struct Guard<float> { static constexpr bool on = true; };
+
+// src/aabb.rs:30-46 with the three reciprocals hoisted out (the reference recomputes 1/d per box; same values).
+template <class R> RT_DEV bool aabb_hit(const DLink<R>& b, const Ray<R>& ray, V3<R> inv_d, R t_min, R t_max) {
+  bool ok = true;
+  {
+    R t0 = (b.bmin[0] - ray.o.x) * inv_d.x, t1 = (b.bmax[0] - ray.o.x) * inv_d.x;
+    if (inv_d.x < (R)0) { R s = t0; t0 = t1; t1 = s; }
+    t_min = t0 > t_min ? t0 : t_min;
+    t_max = t1 < t_max ? t1 : t_max;
+    ok = ok && !(t_max <= t_min);
+  }
+  {
+    R t0 = (b.bmin[1] - ray.o.y) * inv_d.y, t1 = (b.bmax[1] - ray.o.y) * inv_d.y;
+    if (inv_d.y < (R)0) { R s = t0; t0 = t1; t1 = s; }
+    t_min = t0 > t_min ? t0 : t_min;
+    t_max = t1 < t_max ? t1 : t_max;
+    ok = ok && !(t_max <= t_min);
+  }
+  {
+    R t0 = (b.bmin[2] - ray.o.z) * inv_d.z, t1 = (b.bmax[2] - ray.o.z) * inv_d.z;
+    if (inv_d.z < (R)0) { R s = t0; t0 = t1; t1 = s; }
+    t_min = t0 > t_min ? t0 : t_min;
+    t_max = t1 < t_max ? t1 : t_max;
+    ok = ok && !(t_max <= t_min);
+  }
+  return ok;
+}
+
+// Quadratic of src/sphere.rs:45-62 for a sphere at `center`.  Double precision: the reference's expressions as written.
+RT_DEV bool sphere_roots(V3<double> center, const Ray<double>& ray, double radius, double t_min, double t_max, double& root, bool) {
+  V3<double> oc = ray.o - center;
+  double a = length_squared(ray.d);
+  double half_b = dot(oc, ray.d);
+  double c = length_squared(oc) - radius * radius;
+  double discriminant = half_b * half_b - a * c;
+  if (discriminant < 0.0) return false;
+  double sqrt_d = rt_sqrt(discriminant);
+  root = (-half_b - sqrt_d) / a;
+  if (root < t_min || t_max < root) {
+    root = (-half_b + sqrt_d) / a;
+    if (root < t_min || t_max < root) return false;
+  }
+  return true;
+}
+// Single precision: `half_b^2 - a*c` cancels catastrophically for the radius-1000 ground spheres and for spheres far from
+// the ray origin, so oc, the three coefficients, the discriminant and the numerator -half_b -/+ sqrt(D) are formed in f64
+// from the f32 inputs (products of floats are exact in double); the square root and the division stay in f32.
+RT_DEV bool sphere_roots(V3<float> center, const Ray<float>& ray, float radius, float t_min, float t_max, float& root, bool on_surface) {
+  double ocx = (double)ray.o.x - (double)center.x, ocy = (double)ray.o.y - (double)center.y, ocz = (double)ray.o.z - (double)center.z;
+  double dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+  double a = dx * dx + dy * dy + dz * dz;
+  double half_b = ocx * dx + ocy * dy + ocz * dz;
+  double c = ocx * ocx + ocy * ocy + ocz * ocz - (double)radius * (double)radius;
+  if (on_surface) c = 0.0;  // the ray starts on this sphere: see Origin
+  double discriminant = half_b * half_b - a * c;
+  if (discriminant < 0.0) return false;
+  float sqrt_d = rt_sqrt((float)discriminant);
+  float af = (float)a;
+  root = (float)(-half_b - (double)sqrt_d) / af;
+  if (root < t_min || t_max < root) {
+    root = (float)(-half_b + (double)sqrt_d) / af;
+    if (root < t_min || t_max < root) return false;
+  }
+  return true;
+}
+
+// One axis-aligned rectangle.  AXIS is the constant axis; (A, B) the in-plane axes in the reference's (u, v) order.
+template <class R, int AXIS>
+RT_DEV bool rect_hit(R a0, R a1, R b0, R b1, R k, int material, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec) {  // src/aarect.rs:88-107
+  constexpr int A = (AXIS == 0) ? 1 : 0;
+  constexpr int B = (AXIS == 2) ? 1 : 2;
+  const R o[3] = {ray.o.x, ray.o.y, ray.o.z};
+  const R d[3] = {ray.d.x, ray.d.y, ray.d.z};
+  R t = (k - o[AXIS]) / d[AXIS];
+  if (t < t_min || t > t_max) return false;
+  R a = o[A] + t * d[A];
+  R b = o[B] + t * d[B];
+  if (a < a0 || a > a1 || b < b0 || b > b1) return false;
+  rec.u = (a - a0) / (a1 - a0);
+  rec.v = (b - b0) / (b1 - b0);
+  rec.uv_lazy = 0;
+  rec.t = t;
+  V3<R> outward(AXIS == 0 ? (R)1 : (R)0, AXIS == 1 ? (R)1 : (R)0, AXIS == 2 ? (R)1 : (R)0);
+  rec.set_face_normal(ray.d, outward);
+  rec.mat = material;
+  rec.p = ray.at(t);
+  if constexpr (Guard<R>::on) {  // the hit point lies in the plane: o[AXIS] + t*d[AXIS] is k up to rounding, f64 keeps 1e-13 of it, f32 does not
+    if (AXIS == 0) rec.p.x = k;
+    if (AXIS == 1) rec.p.y = k;
+    if (AXIS == 2) rec.p.z = k;
+  }
+  return true;
+}
+
+template <class R> RT_DEV V3<R> moving_center(const DShape<R>& s, R time) {  // src/moving_sphere.rs:37-40
+  V3<R> c0(s.p[0], s.p[1], s.p[2]), c1(s.p[3], s.p[4], s.p[5]);
+  return c0 + ((time - s.p[7]) / (s.p[8] - s.p[7])) * (c1 - c0);
+}
+
+// `self_side`: -2 when the ray does not start on this object, otherwise the side it starts on (-1 for one-sided shapes).
+template <class R> RT_DEV bool shape_hit(const DShape<R>& s, int leaf, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, int self_side) {
+  bool hit = false;
+  const bool self = Guard<R>::on && self_side != -2;
+  switch (s.tag) {
+    case SH_SPHERE: {  // src/sphere.rs:38-73
+      V3<R> center(s.p[0], s.p[1], s.p[2]);
+      R radius = s.p[3], root;
+      if (sphere_roots(center, ray, radius, t_min, t_max, root, self)) {
+        V3<R> p = ray.at(root);
+        V3<R> outward = vdiv(p - center, radius);
+        rec.t = root;
+        rec.p = p;
+        rec.set_face_normal(ray.d, outward);
+        rec.mat = s.material;
+        rec.u = outward.x; rec.v = outward.y; rec.uw = outward.z; rec.uv_lazy = 1;
+        rec.side = -1;
+        hit = true;
+      }
+      break;
+    }
+    case SH_MOVING: {  // src/moving_sphere.rs:44-72 (u, v are not written)
+      V3<R> center = moving_center(s, ray.time);
+      R radius = s.p[6], root;
+      if (sphere_roots(center, ray, radius, t_min, t_max, root, self)) {
+        V3<R> p = ray.at(root);
+        V3<R> outward = vdiv(p - moving_center(s, ray.time), radius);
+        rec.t = root;
+        rec.p = p;
+        rec.set_face_normal(ray.d, outward);
+        rec.mat = s.material;
+        rec.side = -1;
+        hit = true;
+      }
+      break;
+    }
+    case SH_RECT_XY: hit = !self && rect_hit<R, 2>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], s.material, ray, t_min, t_max, rec); if (hit) rec.side = -1; break;
+    case SH_RECT_XZ: hit = !self && rect_hit<R, 1>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], s.material, ray, t_min, t_max, rec); if (hit) rec.side = -1; break;
+    case SH_RECT_YZ: hit = !self && rect_hit<R, 0>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], s.material, ray, t_min, t_max, rec); if (hit) rec.side = -1; break;
+    case SH_BOX: {
+      // Six sides in the order of src/box_struct.rs:22-71, closest wins, a later side wins a tie
+      // (src/hittable_list.rs:29-43: each success shrinks closest_so_far and overwrites the record).
+      R lox = s.p[0], loy = s.p[1], loz = s.p[2], hix = s.p[3], hiy = s.p[4], hiz = s.p[5];
+      R closest = t_max;
+      if (!(self && self_side == 0) && rect_hit<R, 2>(lox, hix, loy, hiy, hiz, s.material, ray, t_min, closest, rec)) { closest = rec.t; rec.side = 0; hit = true; }
+      if (!(self && self_side == 1) && rect_hit<R, 2>(lox, hix, loy, hiy, loz, s.material, ray, t_min, closest, rec)) { closest = rec.t; rec.side = 1; hit = true; }
+      if (!(self && self_side == 2) && rect_hit<R, 1>(lox, hix, loz, hiz, hiy, s.material, ray, t_min, closest, rec)) { closest = rec.t; rec.side = 2; hit = true; }
+      if (!(self && self_side == 3) && rect_hit<R, 1>(lox, hix, loz, hiz, loy, s.material, ray, t_min, closest, rec)) { closest = rec.t; rec.side = 3; hit = true; }
+      if (!(self && self_side == 4) && rect_hit<R, 0>(loy, hiy, loz, hiz, hix, s.material, ray, t_min, closest, rec)) { closest = rec.t; rec.side = 4; hit = true; }
+      if (!(self && self_side == 5) && rect_hit<R, 0>(loy, hiy, loz, hiz, lox, s.material, ray, t_min, closest, rec)) { closest = rec.t; rec.side = 5; hit = true; }
+      break;
+    }
+    default: break;
+  }
+  if (hit) { rec.obj = s.obj_id; rec.sub = s.sub_id; rec.leaf = leaf; }
+  return hit;
+}
+
+template <class R, bool L, int LEVEL>
+RT_DEV bool traverse(const SceneView<R, L>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org);
+
+// [Translate(] [RotateY(] geometry [))] — the part of an object below an optional ConstantMedium.
+template <class R, bool L, int LEVEL>
+RT_DEV bool boundary_hit(const SceneView<R, L>& sv, const DObject<R>& ob, int obj_index, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec,
+                         Stream& media, Origin org) {
+  Ray<R> moved = ray;
+  if (ob.flags & OBJ_TRANSLATE) moved.o = ray.o - V3<R>(ob.offset[0], ob.offset[1], ob.offset[2]);  // src/hittable.rs:141
+  Ray<R> local = moved;
+  if (ob.flags & OBJ_ROTATE_Y) {  // src/hittable.rs:214-223 (ray time forced to 0)
+    local.o.x = ob.cos_theta * moved.o.x - ob.sin_theta * moved.o.z;
+    local.o.z = ob.sin_theta * moved.o.x + ob.cos_theta * moved.o.z;
+    local.d.x = ob.cos_theta * moved.d.x - ob.sin_theta * moved.d.z;
+    local.d.z = ob.sin_theta * moved.d.x + ob.cos_theta * moved.d.z;
+    local.time = (R)0;
+  }
+  bool hit;
+  if (ob.flags & OBJ_SUB_BVH) {
+    if constexpr (LEVEL == 0) hit = traverse<R, L, 1>(sv, ob.sub_root, local, t_min, t_max, rec, media, org);
+    else hit = false;  // nested trees do not nest further (rejected at upload)
+  } else {
+    hit = shape_hit(sv.shapes[obj_index], obj_index, local, t_min, t_max, rec, org.leaf() == obj_index ? org.side() : -2);
+  }
+  if (!hit) return false;
+  if (ob.flags & OBJ_ROTATE_Y) {  // src/hittable.rs:229-239
+    V3<R> p = rec.p, n = rec.n;
+    p.x = ob.cos_theta * rec.p.x + ob.sin_theta * rec.p.z;
+    p.z = -ob.sin_theta * rec.p.x + ob.cos_theta * rec.p.z;
+    n.x = ob.cos_theta * rec.n.x + ob.sin_theta * rec.n.z;
+    n.z = -ob.sin_theta * rec.n.x + ob.cos_theta * rec.n.z;
+    rec.p = p;
+    rec.set_face_normal(local.d, n);  // object-space direction against a world-space normal, as the reference does
+  }
+  if (ob.flags & OBJ_TRANSLATE) {  // src/hittable.rs:146-148
+    rec.p = rec.p + V3<R>(ob.offset[0], ob.offset[1], ob.offset[2]);
+    rec.set_face_normal(moved.d, rec.n);
+  }
+  return true;
+}
+
+template <class R, bool L, int LEVEL>
+RT_DEV bool object_hit(const SceneView<R, L>& sv, int obj_index, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
+  const DObject<R> ob = sv.objects[obj_index];
+  if (!(ob.flags & OBJ_MEDIUM)) return boundary_hit<R, L, LEVEL>(sv, ob, obj_index, ray, t_min, t_max, rec, media, org);
+  // src/constant_medium.rs:41-111
+  const R inf = Lim<R>::inf();
+  Rec<R> rec1, rec2;
+  if (!boundary_hit<R, L, LEVEL>(sv, ob, obj_index, ray, -inf, inf, rec1, media, Origin())) return false;
+  R t_after = rec1.t + (R)0.0001;
+  if constexpr (Guard<R>::on) {
+    // f32: beyond |t| = 1024 the spacing of floats exceeds 0.0001 and the sum rounds back to rec1.t (a fog boundary of
+    // radius 5000 has t of that size); "strictly beyond the entry point" is what the reference's f64 sum means there.
+    if (!(t_after > rec1.t)) t_after = nextafterf(rec1.t, Lim<float>::inf());
+  }
+  if (!boundary_hit<R, L, LEVEL>(sv, ob, obj_index, ray, t_after, inf, rec2, media, Origin())) return false;
+  R t1 = rec1.t, t2 = rec2.t;
+  if (t1 < t_min) t1 = t_min;
+  if (t2 > t_max) t2 = t_max;
+  if (t1 >= t2) return false;
+  if (t1 < (R)0) t1 = (R)0;
+  R ray_length = length(ray.d);
+  R distance_inside_boundary = (t2 - t1) * ray_length;
+  R hit_distance = ob.neg_inv_density * gen_log01(media, (R)0);
+  if (hit_distance > distance_inside_boundary) return false;
+  rec.t = t1 + hit_distance / ray_length;
+  rec.p = ray.at(rec.t);
+  rec.n = V3<R>((R)1, (R)0, (R)0);
+  rec.front = 1;
+  rec.mat = ob.medium_material;  // u, v untouched
+  rec.obj = sv.shapes[obj_index].obj_id;
+  rec.sub = sv.shapes[obj_index].sub_id;
+  rec.side = -1;
+  rec.leaf = -1;
+  return true;
+}
+
+// BVHNode::hit (src/bvh.rs:108-119) over the threaded list.  The running `closest` is the t_max every
+// node of the reference's recursion would receive: it starts as the caller's t_max and becomes rec.t
+// after each accepted leaf, and nodes are visited in the reference's left-then-right order.
+template <class R, bool L, int LEVEL>
+RT_DEV bool traverse(const SceneView<R, L>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
+  V3<R> inv_d((R)1 / ray.d.x, (R)1 / ray.d.y, (R)1 / ray.d.z);
+  R closest = t_max;
+  bool any = false;
+  int i = start;
+  while (i >= 0) {
+    const DLink<R> lk = sv.link(i);
+    if (lk.hit & LEAF_FLAG) {
+      int obj = (int)(lk.hit & LEAF_INDEX_MASK);
+      bool h;
+      if (lk.hit & LEAF_SIMPLE) h = shape_hit(sv.shapes[obj], obj, ray, t_min, closest, rec, org.leaf() == obj ? org.side() : -2);
+      else h = object_hit<R, L, LEVEL>(sv, obj, ray, t_min, closest, rec, media, org);
+      if (h) { closest = rec.t; any = true; }
+      i = lk.miss;
+    } else {
+      i = aabb_hit(lk, ray, inv_d, t_min, closest) ? (int)lk.hit : lk.miss;
+    }
+  }
+  return any;
+}
+
+}  // namespace rtd

@@ -1,0 +1,363 @@
+// Kernels of the wavefront path tracer (one lane per ray, 64-wide wavefronts, persistent grid-stride
+// workgroups).  Replaces the worker closure of render_with_threadpool (src/render.rs:224-243) and the
+// ray_color recursion (src/render.rs:149-177): the recursion `E + A * ray_color(scattered, depth - 1)` is
+// unrolled into per-bounce ray queues carrying the running product of attenuations (`throughput`), and
+// every term `throughput * E` is added to the pixel's accumulation slot as soon as it is known.
+#pragma once
+#include "device_shade.h"
+
+namespace rtd {
+
+template <class R> struct Vec4;
+template <> struct Vec4<float> { using type = float4; };
+template <> struct Vec4<double> { using type = double4; };
+
+RT_DEV float bits_to_real(uint32_t lo, uint32_t, float) { return __uint_as_float(lo); }
+RT_DEV double bits_to_real(uint32_t lo, uint32_t hi, double) { return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo)); }
+RT_DEV uint32_t real_lo_bits(float x) { return __float_as_uint(x); }
+RT_DEV uint32_t real_lo_bits(double x) { return (uint32_t)(uint64_t)__double_as_longlong(x); }
+
+// Ray queue, structure of arrays of 4-vectors: a = (origin, time), b = (direction, pixel bits), c = (throughput, sample bits).
+template <class R> struct PathQueue {
+  using R4 = typename Vec4<R>::type;
+  R4* a;
+  R4* b;
+  R4* c;
+  uint32_t* org;  // Origin bits of every ray (read and written by the single-precision kernels only)
+};
+
+template <class R> struct PathState {
+  Ray<R> ray;
+  V3<R> thr;
+  uint32_t pixel, sample;
+  Origin org;
+};
+
+template <class R> RT_DEV PathState<R> load_path(const PathQueue<R>& q, uint32_t i) {
+  typename Vec4<R>::type a = q.a[i], b = q.b[i], c = q.c[i];
+  PathState<R> s;
+  s.ray.o = V3<R>(a.x, a.y, a.z);
+  s.ray.time = a.w;
+  s.ray.d = V3<R>(b.x, b.y, b.z);
+  s.pixel = real_lo_bits(b.w);
+  s.thr = V3<R>(c.x, c.y, c.z);
+  s.sample = real_lo_bits(c.w);
+  if constexpr (Guard<R>::on) s.org = Origin(q.org[i]);
+  return s;
+}
+template <class R> RT_DEV void store_path(const PathQueue<R>& q, uint32_t i, const PathState<R>& s) {
+  typename Vec4<R>::type a, b, c;
+  a.x = s.ray.o.x; a.y = s.ray.o.y; a.z = s.ray.o.z; a.w = s.ray.time;
+  b.x = s.ray.d.x; b.y = s.ray.d.y; b.z = s.ray.d.z; b.w = bits_to_real(s.pixel, 0u, (R)0);
+  c.x = s.thr.x; c.y = s.thr.y; c.z = s.thr.z; c.w = bits_to_real(s.sample, 0u, (R)0);
+  q.a[i] = a; q.b[i] = b; q.c[i] = c;
+  if constexpr (Guard<R>::on) q.org[i] = s.org.bits;
+}
+
+// Wave-level stream compaction: every lane with `keep` receives a unique slot; one atomic per wave.
+RT_DEV uint32_t compact_slot(bool keep, uint32_t* counter) {
+  unsigned long long mask = __ballot(keep);
+  uint32_t lane_prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+  uint32_t total = (uint32_t)__popcll(mask);
+  uint32_t base = 0;
+  if (total != 0u) {
+    int leader = __ffsll((long long)mask) - 1;
+    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(counter, total);
+    base = (uint32_t)__shfl((int)base, leader, 64);
+  }
+  return base + lane_prefix;
+}
+
+template <class R> RT_DEV void add_radiance(R* accum, uint32_t pixel, V3<R> c) {
+  if (c.x != (R)0 || c.y != (R)0 || c.z != (R)0) {
+    R* px = accum + (size_t)pixel * 4u;
+    atomicAdd(px + 0, c.x);
+    atomicAdd(px + 1, c.y);
+    atomicAdd(px + 2, c.z);
+  }
+}
+
+struct FrameParams {
+  uint32_t width, height, n_pixels;
+  uint32_t sample_base;  // first sample index of this pass
+  uint32_t n_paths;      // n_pixels * samples in this pass
+  uint32_t max_depth;
+  uint64_t seed;
+};
+
+// Primary rays for one pass: path index = sample_in_pass * n_pixels + pixel, so adjacent lanes hold adjacent pixels.
+template <class R>
+__global__ __launch_bounds__(256) void k_gen_primary(DeviceScene<R> sc, FrameParams fp, PathQueue<R> out, uint32_t* counters) {
+  uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < fp.n_paths; i += stride) {
+    uint32_t s = i / fp.n_pixels;
+    uint32_t pixel = i - s * fp.n_pixels;
+    PathState<R> st;
+    st.pixel = pixel;
+    st.sample = fp.sample_base + s;
+    st.ray = primary_ray<R>(sc.camera, fp.width, fp.height, pixel, st.sample, fp.seed);
+    st.thr = V3<R>((R)1, (R)1, (R)1);
+    st.org = Origin();
+    store_path(out, i, st);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) counters[0] = fp.n_paths;
+}
+
+// One bounce for every queued ray: closest hit, miss shader or emitted + scatter, compaction into the next queue.
+template <class R, bool LDS_ALL>
+__global__ __launch_bounds__(256) void k_bounce_fused(DeviceScene<R> sc, FrameParams fp, PathQueue<R> in, PathQueue<R> out,
+                                                      uint32_t* counters, unsigned long long* ray_count, R* accum, uint32_t bounce) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const uint32_t n_in = counters[bounce];
+  if (blockIdx.x * blockDim.x >= n_in) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_count, (unsigned long long)n_in);
+  const SceneView<R, LDS_ALL> sv = make_view<R, LDS_ALL>(sc, lds);
+  const bool last = bounce + 1u >= fp.max_depth;  // ray_color(depth == 0) contributes nothing (src/render.rs:151-153)
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < n_in; base += stride) {
+    uint32_t i = base + threadIdx.x;
+    bool alive = false;
+    PathState<R> st;
+    if (i < n_in) {
+      st = load_path(in, i);
+      Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
+      Rec<R> rec;
+      if (!traverse<R, LDS_ALL, 0>(sv, sc.root_link, st.ray, (R)0.001, Lim<R>::inf(), rec, media, st.org)) {
+        add_radiance(accum, st.pixel, st.thr * background_color(sc.background, st.ray.d));
+      } else {
+        Stream rng(fp.seed, st.pixel, st.sample, bounce, STAGE_SCATTER);
+        V3<R> emitted, attenuation;
+        Ray<R> scattered;
+        alive = shade_hit<R, LDS_ALL>(sv, st.ray, rec, rng, emitted, attenuation, scattered);
+        add_radiance(accum, st.pixel, st.thr * emitted);
+        if (alive) {
+          st.thr = st.thr * attenuation;
+          st.ray = scattered;
+          st.org = Origin(rec.leaf, rec.side);
+        }
+      }
+    }
+    if (!last) {
+      uint32_t slot = compact_slot(alive, counters + bounce + 1u);
+      if (alive) store_path(out, slot, st);
+    }
+  }
+}
+
+// ---- material-sorted pipeline: trace kernel + shade kernel ----
+template <class R> struct HitQueue {
+  using R4 = typename Vec4<R>::type;
+  R4* a;  // p, t
+  R4* b;  // n, (front | mat << 1) bits
+  R4* c;  // u, v, Origin bits of the surface hit, unused
+};
+
+// class_counters: MAT_CLASSES counters for this bounce; class_index[cls * capacity + k] = ray index.
+template <class R, bool LDS_ALL>
+__global__ __launch_bounds__(256) void k_trace(DeviceScene<R> sc, FrameParams fp, PathQueue<R> in, HitQueue<R> hits, uint32_t* counters,
+                                               unsigned long long* ray_count, uint32_t* class_counters, uint32_t* class_index,
+                                               uint32_t capacity, R* accum, uint32_t bounce) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const uint32_t n_in = counters[bounce];
+  if (blockIdx.x * blockDim.x >= n_in) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_count, (unsigned long long)n_in);
+  const SceneView<R, LDS_ALL> sv = make_view<R, LDS_ALL>(sc, lds);
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < n_in; base += stride) {
+    uint32_t i = base + threadIdx.x;
+    int cls = -1;
+    if (i < n_in) {
+      PathState<R> st = load_path(in, i);
+      Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
+      Rec<R> rec;
+      if (!traverse<R, LDS_ALL, 0>(sv, sc.root_link, st.ray, (R)0.001, Lim<R>::inf(), rec, media, st.org)) {
+        add_radiance(accum, st.pixel, st.thr * background_color(sc.background, st.ray.d));
+      } else {
+        rec.finish_uv();
+        cls = sv.materials[rec.mat].tag;
+        typename Vec4<R>::type a, b, c;
+        a.x = rec.p.x; a.y = rec.p.y; a.z = rec.p.z; a.w = rec.t;
+        b.x = rec.n.x; b.y = rec.n.y; b.z = rec.n.z; b.w = bits_to_real((uint32_t)rec.front | ((uint32_t)rec.mat << 1), 0u, (R)0);
+        c.x = rec.u; c.y = rec.v; c.z = bits_to_real(Origin(rec.leaf, rec.side).bits, 0u, (R)0); c.w = (R)0;
+        hits.a[i] = a; hits.b[i] = b; hits.c[i] = c;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < MAT_CLASSES; ++k) {
+      bool mine = cls == k;
+      if (__ballot(mine) != 0ull) {
+        uint32_t slot = compact_slot(mine, class_counters + k);
+        if (mine) class_index[(size_t)k * capacity + slot] = i;
+      }
+    }
+  }
+}
+
+template <class R, bool LDS_ALL>
+__global__ __launch_bounds__(256) void k_shade(DeviceScene<R> sc, FrameParams fp, PathQueue<R> in, HitQueue<R> hits, PathQueue<R> out,
+                                               uint32_t* counters, const uint32_t* class_counters, const uint32_t* class_index,
+                                               uint32_t capacity, R* accum, uint32_t bounce) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  uint32_t cls_end[MAT_CLASSES];
+  uint32_t total = 0;
+#pragma unroll
+  for (int k = 0; k < MAT_CLASSES; ++k) {
+    total += class_counters[k];
+    cls_end[k] = total;
+  }
+  if (blockIdx.x * blockDim.x >= total) return;
+  const SceneView<R, LDS_ALL> sv = make_view<R, LDS_ALL>(sc, lds);
+  const bool last = bounce + 1u >= fp.max_depth;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < total; base += stride) {
+    uint32_t w = base + threadIdx.x;
+    bool alive = false;
+    PathState<R> st;
+    if (w < total) {
+      // work item w belongs to the first class whose cumulative end exceeds it
+      uint32_t cls = 0, begin = 0;
+#pragma unroll
+      for (int k = 0; k < MAT_CLASSES - 1; ++k)
+        if (w >= cls_end[k]) { cls = (uint32_t)k + 1u; begin = cls_end[k]; }
+      uint32_t i = class_index[(size_t)cls * capacity + (w - begin)];
+      st = load_path(in, i);
+      typename Vec4<R>::type a = hits.a[i], b = hits.b[i], c = hits.c[i];
+      Rec<R> rec;
+      rec.p = V3<R>(a.x, a.y, a.z); rec.t = a.w;
+      rec.n = V3<R>(b.x, b.y, b.z);
+      uint32_t bits = real_lo_bits(b.w);
+      rec.front = (int32_t)(bits & 1u); rec.mat = (int32_t)(bits >> 1);
+      rec.u = c.x; rec.v = c.y; rec.uv_lazy = 0;
+      const Origin hit_surface(real_lo_bits(c.z));
+      Stream rng(fp.seed, st.pixel, st.sample, bounce, STAGE_SCATTER);
+      V3<R> emitted, attenuation;
+      Ray<R> scattered;
+      alive = shade_hit<R, LDS_ALL>(sv, st.ray, rec, rng, emitted, attenuation, scattered);
+      add_radiance(accum, st.pixel, st.thr * emitted);
+      if (alive) {
+        st.thr = st.thr * attenuation;
+        st.ray = scattered;
+        st.org = hit_surface;
+      }
+    }
+    if (!last) {
+      uint32_t slot = compact_slot(alive, counters + bounce + 1u);
+      if (alive) store_path(out, slot, st);
+    }
+  }
+}
+
+// ---- resolve: color_to_pixel over the accumulation buffer (src/color.rs:14-33), evaluated in f64 ----
+template <class R> __global__ void k_resolve(const R* accum, uint32_t n_pixels, uint32_t spp, uint8_t* rgb) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pixels) return;
+  double scale = 1.0 / (double)spp;
+  rgb[i * 3u + 0] = to_u8<double>((double)accum[(size_t)i * 4u + 0], scale);
+  rgb[i * 3u + 1] = to_u8<double>((double)accum[(size_t)i * 4u + 1], scale);
+  rgb[i * 3u + 2] = to_u8<double>((double)accum[(size_t)i * 4u + 2], scale);
+}
+
+// ---- test / inspection entry points ----
+struct RayIO {  // = rt_ray
+  double o[3], d[3], time, tmin, tmax;
+  uint32_t pixel, sample, bounce, pad;
+};
+struct HitIO {  // = rt_hit
+  int32_t hit, obj, sub, side, material, front_face;
+  double t, p[3], n[3], u, v;
+};
+
+template <class R, bool LDS_ALL>
+__global__ __launch_bounds__(256) void k_first_hit(DeviceScene<R> sc, const RayIO* rays, uint32_t n, HitIO* hits, uint64_t seed) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const SceneView<R, LDS_ALL> sv = make_view<R, LDS_ALL>(sc, lds);
+  uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    RayIO r = rays[i];
+    Ray<R> ray;
+    ray.o = V3<R>((R)r.o[0], (R)r.o[1], (R)r.o[2]);
+    ray.d = V3<R>((R)r.d[0], (R)r.d[1], (R)r.d[2]);
+    ray.time = (R)r.time;
+    Stream media(seed, r.pixel, r.sample, r.bounce, STAGE_MEDIA);
+    Rec<R> rec;
+    bool h = traverse<R, LDS_ALL, 0>(sv, sc.root_link, ray, (R)r.tmin, (R)r.tmax, rec, media, Origin());
+    HitIO o;
+    o.hit = h ? 1 : 0;
+    if (h) {
+      rec.finish_uv();
+      o.obj = rec.obj; o.sub = rec.sub; o.side = rec.side; o.material = rec.mat; o.front_face = rec.front;
+      o.t = (double)rec.t; o.u = (double)rec.u; o.v = (double)rec.v;
+      o.p[0] = (double)rec.p.x; o.p[1] = (double)rec.p.y; o.p[2] = (double)rec.p.z;
+      o.n[0] = (double)rec.n.x; o.n[1] = (double)rec.n.y; o.n[2] = (double)rec.n.z;
+    } else {
+      o.obj = o.sub = o.side = o.material = -1; o.front_face = 0;
+      o.t = o.u = o.v = 0.0;
+      o.p[0] = o.p[1] = o.p[2] = o.n[0] = o.n[1] = o.n[2] = 0.0;
+    }
+    hits[i] = o;
+  }
+}
+
+template <class R>
+__global__ void k_camera_rays(DeviceScene<R> sc, uint32_t W, uint32_t H, const uint32_t* pixel, const uint32_t* sample, uint32_t n,
+                              uint64_t seed, RayIO* out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Ray<R> ray = primary_ray<R>(sc.camera, W, H, pixel[i], sample[i], seed);
+  RayIO r;
+  r.o[0] = (double)ray.o.x; r.o[1] = (double)ray.o.y; r.o[2] = (double)ray.o.z;
+  r.d[0] = (double)ray.d.x; r.d[1] = (double)ray.d.y; r.d[2] = (double)ray.d.z;
+  r.time = (double)ray.time; r.tmin = 0.001; r.tmax = __builtin_inf();
+  r.pixel = pixel[i]; r.sample = sample[i]; r.bounce = 0; r.pad = 0;
+  out[i] = r;
+}
+
+// Whole path in one thread (one lane follows one camera sample to termination).  Used to compare single samples
+// with a CPU evaluation; the render path uses the queue kernels above.
+template <class R, bool LDS_ALL>
+__global__ __launch_bounds__(256) void k_sample_radiance(DeviceScene<R> sc, uint32_t W, uint32_t H, uint32_t max_depth, const uint32_t* pixel,
+                                                         const uint32_t* sample, uint32_t n, uint64_t seed, double* out, double* path_out,
+                                                         uint32_t max_vertices) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const SceneView<R, LDS_ALL> sv = make_view<R, LDS_ALL>(sc, lds);
+  uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    uint32_t px = pixel[i], sm = sample[i];
+    Ray<R> ray = primary_ray<R>(sc.camera, W, H, px, sm, seed);
+    V3<R> thr((R)1, (R)1, (R)1), sum((R)0, (R)0, (R)0);
+    uint32_t n_rays = 0;
+    Origin org;
+    for (uint32_t bounce = 0; bounce < max_depth; ++bounce) {
+      ++n_rays;
+      Stream media(seed, px, sm, bounce, STAGE_MEDIA);
+      Rec<R> rec;
+      bool hit = traverse<R, LDS_ALL, 0>(sv, sc.root_link, ray, (R)0.001, Lim<R>::inf(), rec, media, org);
+      if (path_out && bounce < max_vertices) {  // one vertex = origin(3) direction(3) t obj sub material front hit
+        double* v = path_out + ((size_t)i * max_vertices + bounce) * 12u;
+        v[0] = (double)ray.o.x; v[1] = (double)ray.o.y; v[2] = (double)ray.o.z;
+        v[3] = (double)ray.d.x; v[4] = (double)ray.d.y; v[5] = (double)ray.d.z;
+        v[6] = hit ? (double)rec.t : 0.0; v[7] = hit ? (double)rec.obj : -1.0; v[8] = hit ? (double)rec.sub : -1.0;
+        v[9] = hit ? (double)rec.mat : -1.0; v[10] = hit ? (double)rec.front : 0.0; v[11] = hit ? 1.0 : 0.0;
+      }
+      if (!hit) {
+        sum = sum + thr * background_color(sc.background, ray.d);
+        break;
+      }
+      Stream rng(seed, px, sm, bounce, STAGE_SCATTER);
+      V3<R> emitted, attenuation;
+      Ray<R> scattered;
+      bool alive = shade_hit<R, LDS_ALL>(sv, ray, rec, rng, emitted, attenuation, scattered);
+      sum = sum + thr * emitted;
+      if (!alive) break;
+      thr = thr * attenuation;
+      ray = scattered;
+      org = Origin(rec.leaf, rec.side);
+    }
+    out[(size_t)i * 4u + 0] = (double)sum.x;
+    out[(size_t)i * 4u + 1] = (double)sum.y;
+    out[(size_t)i * 4u + 2] = (double)sum.z;
+    out[(size_t)i * 4u + 3] = (double)n_rays;
+  }
+}
+
+}  // namespace rtd

@@ -1,0 +1,320 @@
+// Host-side launch code for one arithmetic type; included by rt_f32.hip and rt_f64.hip, which instantiate it.
+#pragma once
+#include "context.h"
+#include "kernels.h"
+
+namespace rti {
+
+static_assert(sizeof(RayIO) == sizeof(rt_ray), "rt_ray layout");
+static_assert(sizeof(HitIO) == sizeof(rt_hit), "rt_hit layout");
+static_assert(sizeof(DLink<float>) == 32 && sizeof(DLink<double>) == 64, "link size");
+
+template <class R> R round_down(double x);
+template <class R> R round_up(double x);
+template <> inline double round_down<double>(double x) { return x; }
+template <> inline double round_up<double>(double x) { return x; }
+// single-precision boxes must still contain the double-precision ones
+template <> inline float round_down<float>(double x) {
+  float f = (float)x;
+  return ((double)f > x) ? std::nextafterf(f, -INFINITY) : f;
+}
+template <> inline float round_up<float>(double x) {
+  float f = (float)x;
+  return ((double)f < x) ? std::nextafterf(f, INFINITY) : f;
+}
+
+
+template <class R>
+int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink>& links, int root_link, const std::vector<int>& sub_root_of_object,
+                SceneImage<R>& im) {
+  BlobLayout lay{};
+  uint32_t off = 0;
+  lay.n_links = (uint32_t)links.size();
+  lay.n_objects = (uint32_t)s.n_objects;
+  lay.n_materials = (uint32_t)s.n_materials;
+  lay.n_textures = (uint32_t)std::max(1, s.n_textures);
+  lay.n_perlins = (uint32_t)s.n_perlins;
+  lay.links_off = off; off = align16(off + lay.n_links * (uint32_t)sizeof(DLink<R>));
+  lay.shapes_off = off; off = align16(off + lay.n_objects * (uint32_t)sizeof(DShape<R>));
+  lay.objects_off = off; off = align16(off + lay.n_objects * (uint32_t)sizeof(DObject<R>));
+  lay.materials_off = off; off = align16(off + lay.n_materials * (uint32_t)sizeof(DMaterial<R>));
+  lay.textures_off = off; off = align16(off + lay.n_textures * (uint32_t)sizeof(DTexture<R>));
+  lay.perlins_off = off; off = align16(off + lay.n_perlins * (uint32_t)sizeof(DPerlin<R>));
+  lay.total_bytes = off;
+  std::vector<uint8_t> blob(off, 0);
+  auto* L = reinterpret_cast<DLink<R>*>(blob.data() + lay.links_off);
+  for (size_t i = 0; i < links.size(); ++i) {
+    for (int k = 0; k < 3; ++k) { L[i].bmin[k] = round_down<R>(links[i].bmin[k]); L[i].bmax[k] = round_up<R>(links[i].bmax[k]); }
+    L[i].hit = links[i].hit;
+    L[i].miss = links[i].miss;
+  }
+  auto* S = reinterpret_cast<DShape<R>*>(blob.data() + lay.shapes_off);
+  auto* O = reinterpret_cast<DObject<R>*>(blob.data() + lay.objects_off);
+  for (int i = 0; i < s.n_objects; ++i) {
+    const rt_object& o = s.objects[i];
+    S[i].obj_id = o.obj_id; S[i].sub_id = o.sub_id;
+    if (o.flags & RT_OBJ_SUB_BVH) {
+      S[i].tag = -1; S[i].material = -1;
+    } else {
+      const rt_shape& sh = s.shapes[o.geom];
+      S[i].tag = sh.tag; S[i].material = sh.material;
+      for (int k = 0; k < 9; ++k) S[i].p[k] = (R)sh.p[k];
+    }
+    O[i].flags = o.flags;
+    O[i].sub_root = sub_root_of_object[i];
+    O[i].medium_material = o.medium_material;
+    for (int k = 0; k < 3; ++k) O[i].offset[k] = (R)o.offset[k];
+    O[i].sin_theta = (R)o.sin_theta; O[i].cos_theta = (R)o.cos_theta; O[i].neg_inv_density = (R)o.neg_inv_density;
+  }
+  auto* M = reinterpret_cast<DMaterial<R>*>(blob.data() + lay.materials_off);
+  for (int i = 0; i < s.n_materials; ++i) {
+    M[i].tag = s.materials[i].tag; M[i].texture = s.materials[i].texture;
+    for (int k = 0; k < 3; ++k) M[i].albedo[k] = (R)s.materials[i].albedo[k];
+    M[i].fuzz = (R)s.materials[i].fuzz; M[i].ir = (R)s.materials[i].ir;
+  }
+  auto* T = reinterpret_cast<DTexture<R>*>(blob.data() + lay.textures_off);
+  for (int i = 0; i < s.n_textures; ++i) {
+    const rt_texture& t = s.textures[i];
+    T[i].tag = t.tag; T[i].even = t.even; T[i].odd = t.odd; T[i].perlin = t.perlin; T[i].image = t.image;
+    for (int k = 0; k < 3; ++k) T[i].color[k] = (R)t.color[k];
+    T[i].scale = (R)t.scale;
+  }
+  auto* P = reinterpret_cast<DPerlin<R>*>(blob.data() + lay.perlins_off);
+  for (int i = 0; i < s.n_perlins; ++i) {
+    for (int j = 0; j < 256; ++j) {
+      for (int k = 0; k < 3; ++k) P[i].ran[j][k] = (R)s.perlins[i].ran_vec[j][k];
+      P[i].perm[0][j] = s.perlins[i].perm_x[j]; P[i].perm[1][j] = s.perlins[i].perm_y[j]; P[i].perm[2][j] = s.perlins[i].perm_z[j];
+    }
+  }
+  HIP_TRY(hipMalloc((void**)&im.d_blob, blob.size()));
+  HIP_TRY(hipMemcpy(im.d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+  im.lds_all = lay.total_bytes <= kLdsAllMax;
+  DeviceScene<R>& d = im.dev;
+  d.blob = im.d_blob;
+  d.lay = lay;
+  d.images = c->d_images;
+  d.n_images = s.n_images;
+  d.root_link = root_link;
+  d.lds_links = im.lds_all ? 0u : std::min<uint32_t>(lay.n_links, kLdsTopMax / (uint32_t)sizeof(DLink<R>));
+  im.lds_bytes = im.lds_all ? lay.total_bytes : d.lds_links * (uint32_t)sizeof(DLink<R>);
+  auto v3 = [](const double* p) { return V3<R>((R)p[0], (R)p[1], (R)p[2]); };
+  d.camera.origin = v3(s.camera.origin); d.camera.lower_left_corner = v3(s.camera.lower_left_corner);
+  d.camera.horizontal = v3(s.camera.horizontal); d.camera.vertical = v3(s.camera.vertical);
+  d.camera.u = v3(s.camera.u); d.camera.v = v3(s.camera.v);
+  d.camera.lens_radius = (R)s.camera.lens_radius; d.camera.t_open = (R)s.camera.shutter_open_time; d.camera.t_close = (R)s.camera.shutter_close_time;
+  d.background.kind = s.background.kind; d.background.c0 = v3(s.background.c0); d.background.c1 = v3(s.background.c1);
+  return RT_OK;
+}
+
+
+inline int ensure_accum(rt_context* c, size_t bytes) {
+  if (c->accum_bytes >= bytes) return RT_OK;
+  if (c->accum) (void)hipFree(c->accum);
+  c->accum = nullptr; c->accum_bytes = 0;
+  HIP_TRY(hipMalloc(&c->accum, bytes));
+  c->accum_bytes = bytes;
+  return RT_OK;
+}
+inline int ensure_ws(rt_context* c, size_t bytes) {
+  if (c->ws_bytes >= bytes) return RT_OK;
+  if (c->ws) (void)hipFree(c->ws);
+  c->ws = nullptr; c->ws_bytes = 0;
+  HIP_TRY(hipMalloc(&c->ws, bytes));
+  c->ws_bytes = bytes;
+  return RT_OK;
+}
+
+template <class R> int render_accum_impl(rt_context* c, const rt_render_params& p, void* accum_dev, rt_stats* stats) {
+  using R4 = typename Vec4<R>::type;
+  SceneImage<R>& im = image_of<R>(c);
+  const uint64_t n_pixels = (uint64_t)p.width * p.height;
+  const uint32_t n_samples = p.sample_end - p.sample_begin;
+  auto t_begin = std::chrono::steady_clock::now();
+  R* accum = reinterpret_cast<R*>(accum_dev);
+  if (!accum) {
+    int rc = ensure_accum(c, n_pixels * 4 * sizeof(R));
+    if (rc) return rc;
+    accum = reinterpret_cast<R*>(c->accum);
+    HIP_TRY(hipMemsetAsync(accum, 0, n_pixels * 4 * sizeof(R), c->stream));
+  }
+  uint32_t spp_pass = p.samples_per_pass ? p.samples_per_pass : (uint32_t)std::max<uint64_t>(1, kTargetPathsPerPass / n_pixels);
+  spp_pass = std::max(1u, std::min(spp_pass, std::max(1u, n_samples)));
+  if (n_pixels * spp_pass > 0x7FFFFFFFull) return fail(RT_E_INVALID, "width*height*samples_per_pass exceeds 2^31-1");
+  const uint64_t cap = n_pixels * spp_pass;
+  const bool sorted = p.pipeline == RT_PIPELINE_SORTED;
+  // workspace: two ray queues (3 arrays each) [+ hit queue (3 arrays) + class index lists]
+  size_t q_bytes = (size_t)cap * sizeof(R4);
+  size_t ws_bytes = q_bytes * 6 + (((size_t)cap * 4 + 255) & ~(size_t)255) * 2 + (sorted ? q_bytes * 3 + (size_t)cap * 4 * MAT_CLASSES : 0);
+  int rc = ensure_ws(c, ws_bytes);
+  if (rc) return rc;
+  uint8_t* w = reinterpret_cast<uint8_t*>(c->ws);
+  PathQueue<R> q[2];
+  for (int k = 0; k < 2; ++k) {
+    q[k].a = reinterpret_cast<R4*>(w); w += q_bytes;
+    q[k].b = reinterpret_cast<R4*>(w); w += q_bytes;
+    q[k].c = reinterpret_cast<R4*>(w); w += q_bytes;
+  }
+  for (int k = 0; k < 2; ++k) {
+    q[k].org = reinterpret_cast<uint32_t*>(w); w += ((size_t)cap * 4 + 255) & ~(size_t)255;
+  }
+  HitQueue<R> hq{};
+  uint32_t* class_index = nullptr;
+  if (sorted) {
+    hq.a = reinterpret_cast<R4*>(w); w += q_bytes;
+    hq.b = reinterpret_cast<R4*>(w); w += q_bytes;
+    hq.c = reinterpret_cast<R4*>(w); w += q_bytes;
+    class_index = reinterpret_cast<uint32_t*>(w);
+  }
+  uint32_t* counters = c->d_counters;
+  uint32_t* class_counters = c->d_counters + (kMaxDepth + 2);
+  HIP_TRY(hipMemsetAsync(c->d_ray_count, 0, sizeof(unsigned long long), c->stream));
+
+  double bounce_ms = 0.0, gen_ms = 0.0;
+  uint64_t launches = 0, passes = 0;
+  const size_t counter_bytes = sizeof(uint32_t) * ((size_t)(kMaxDepth + 2) + (sorted ? (size_t)(p.max_depth + 1) * 8 : 0));
+  for (uint32_t s0 = p.sample_begin; s0 < p.sample_end; s0 += spp_pass) {
+    uint32_t ns = std::min(spp_pass, p.sample_end - s0);
+    FrameParams fp{};
+    fp.width = p.width; fp.height = p.height; fp.n_pixels = (uint32_t)n_pixels;
+    fp.sample_base = s0; fp.n_paths = (uint32_t)(n_pixels * ns); fp.max_depth = p.max_depth; fp.seed = p.seed;
+    HIP_TRY(hipMemsetAsync(counters, 0, sorted ? counter_bytes : sizeof(uint32_t) * (p.max_depth + 2), c->stream));
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    hipLaunchKernelGGL((k_gen_primary<R>), dim3(grid_for(c, fp.n_paths, 8)), dim3(kBlock), 0, c->stream, im.dev, fp, q[0], counters);
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    const uint32_t grid = grid_for(c, fp.n_paths, 8);
+    for (uint32_t b = 0; b < p.max_depth; ++b) {
+      PathQueue<R>& in = q[b & 1u];
+      PathQueue<R>& out = q[(b + 1u) & 1u];
+      if (!sorted) {
+        if (im.lds_all)
+          hipLaunchKernelGGL((k_bounce_fused<R, true>), dim3(grid), dim3(kBlock), im.lds_bytes, c->stream, im.dev, fp, in, out, counters,
+                             c->d_ray_count, accum, b);
+        else
+          hipLaunchKernelGGL((k_bounce_fused<R, false>), dim3(grid), dim3(kBlock), im.lds_bytes, c->stream, im.dev, fp, in, out, counters,
+                             c->d_ray_count, accum, b);
+        launches += 1;
+      } else {
+        uint32_t* cc = class_counters + (size_t)b * 8;
+        if (im.lds_all) {
+          hipLaunchKernelGGL((k_trace<R, true>), dim3(grid), dim3(kBlock), im.lds_bytes, c->stream, im.dev, fp, in, hq, counters, c->d_ray_count,
+                             cc, class_index, (uint32_t)cap, accum, b);
+          hipLaunchKernelGGL((k_shade<R, true>), dim3(grid), dim3(kBlock), im.lds_bytes, c->stream, im.dev, fp, in, hq, out, counters, cc,
+                             class_index, (uint32_t)cap, accum, b);
+        } else {
+          hipLaunchKernelGGL((k_trace<R, false>), dim3(grid), dim3(kBlock), im.lds_bytes, c->stream, im.dev, fp, in, hq, counters, c->d_ray_count,
+                             cc, class_index, (uint32_t)cap, accum, b);
+          hipLaunchKernelGGL((k_shade<R, false>), dim3(grid), dim3(kBlock), im.lds_bytes, c->stream, im.dev, fp, in, hq, out, counters, cc,
+                             class_index, (uint32_t)cap, accum, b);
+        }
+        launches += 2;
+      }
+    }
+    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventSynchronize(c->ev[2]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    gen_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
+    bounce_ms += ms;
+    ++passes;
+  }
+  unsigned long long rays = 0;
+  HIP_TRY(hipMemcpyAsync(&rays, c->d_ray_count, sizeof(rays), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (stats) {
+    stats->rays = rays;
+    stats->camera_rays = n_pixels * n_samples;
+    stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    stats->bounce_kernel_ms = bounce_ms;
+    stats->bounce_kernel_launches = launches;
+    stats->gen_kernel_ms = gen_ms;
+    stats->passes = passes;
+    stats->lds_bytes = im.lds_bytes;
+    stats->scene_in_lds = im.lds_all ? 1u : 0u;
+  }
+  return RT_OK;
+}
+
+template <class R> int trace_batch_impl(rt_context* c, const rt_ray* rays, size_t n, rt_hit* hits, uint64_t seed) {
+  SceneImage<R>& im = image_of<R>(c);
+  RayIO* d_rays = nullptr;
+  HitIO* d_hits = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_rays, n * sizeof(RayIO)));
+  hipError_t e = hipMalloc((void**)&d_hits, n * sizeof(HitIO));
+  if (e != hipSuccess) { (void)hipFree(d_rays); return fail(RT_E_HIP, "hipMalloc hits failed"); }
+  int rc = RT_OK;
+  do {
+    if (hipMemcpyAsync(d_rays, rays, n * sizeof(RayIO), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(RT_E_HIP, "H2D rays failed"); break; }
+    uint32_t grid = grid_for(c, n, 8);
+    if (im.lds_all) hipLaunchKernelGGL((k_first_hit<R, true>), dim3(grid), dim3(kBlock), im.lds_bytes, c->stream, im.dev, d_rays, (uint32_t)n, d_hits, seed);
+    else hipLaunchKernelGGL((k_first_hit<R, false>), dim3(grid), dim3(kBlock), im.lds_bytes, c->stream, im.dev, d_rays, (uint32_t)n, d_hits, seed);
+    if (hipGetLastError() != hipSuccess) { rc = fail(RT_E_HIP, "k_first_hit launch failed"); break; }
+    if (hipMemcpyAsync(hits, d_hits, n * sizeof(HitIO), hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail(RT_E_HIP, "D2H hits failed"); break; }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(RT_E_HIP, "stream sync failed after k_first_hit"); break; }
+  } while (0);
+  (void)hipFree(d_rays);
+  (void)hipFree(d_hits);
+  return rc;
+}
+
+template <class R>
+int pairs_kernel_impl(rt_context* c, int which, uint32_t W, uint32_t H, uint32_t max_depth, const uint32_t* pixel, const uint32_t* sample, size_t n,
+                      uint64_t seed, void* out, size_t out_bytes) {
+  SceneImage<R>& im = image_of<R>(c);
+  uint32_t *d_px = nullptr, *d_sm = nullptr;
+  void* d_out = nullptr;
+  int rc = RT_OK;
+  do {
+    if (hipMalloc((void**)&d_px, n * 4) != hipSuccess || hipMalloc((void**)&d_sm, n * 4) != hipSuccess || hipMalloc(&d_out, out_bytes) != hipSuccess) {
+      rc = fail(RT_E_HIP, "hipMalloc failed");
+      break;
+    }
+    if (hipMemcpyAsync(d_px, pixel, n * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(d_sm, sample, n * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+      rc = fail(RT_E_HIP, "H2D failed");
+      break;
+    }
+    if (which == 0) {
+      hipLaunchKernelGGL((k_camera_rays<R>), dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, im.dev, W, H, d_px, d_sm, (uint32_t)n,
+                         seed, reinterpret_cast<RayIO*>(d_out));
+    } else {
+      uint32_t grid = grid_for(c, n, 8);
+      // which == 2: `out` receives path vertices (max_vertices * 12 doubles per pair) after the 4 radiance doubles of every pair
+      uint32_t max_vertices = which == 2 ? (uint32_t)((out_bytes / sizeof(double) / n - 4) / 12) : 0u;
+      double* d_path = which == 2 ? reinterpret_cast<double*>(d_out) + n * 4 : nullptr;
+      if (which == 2 && hipMemsetAsync(d_out, 0, out_bytes, c->stream) != hipSuccess) { rc = fail(RT_E_HIP, "memset failed"); break; }
+      if (im.lds_all)
+        hipLaunchKernelGGL((k_sample_radiance<R, true>), dim3(grid), dim3(kBlock), im.lds_bytes, c->stream, im.dev, W, H, max_depth, d_px, d_sm,
+                           (uint32_t)n, seed, reinterpret_cast<double*>(d_out), d_path, max_vertices);
+      else
+        hipLaunchKernelGGL((k_sample_radiance<R, false>), dim3(grid), dim3(kBlock), im.lds_bytes, c->stream, im.dev, W, H, max_depth, d_px, d_sm,
+                           (uint32_t)n, seed, reinterpret_cast<double*>(d_out), d_path, max_vertices);
+    }
+    if (hipGetLastError() != hipSuccess) { rc = fail(RT_E_HIP, "kernel launch failed"); break; }
+    if (hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail(RT_E_HIP, "D2H failed"); break; }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(RT_E_HIP, "stream sync failed"); break; }
+  } while (0);
+  if (d_px) (void)hipFree(d_px);
+  if (d_sm) (void)hipFree(d_sm);
+  if (d_out) (void)hipFree(d_out);
+  return rc;
+}
+
+
+template <class R> int resolve_impl(rt_context* c, const void* accum_dev, size_t n_pixels, uint32_t spp, uint8_t* d_rgb) {
+  uint32_t grid = (uint32_t)((n_pixels + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL((k_resolve<R>), dim3(grid), dim3(kBlock), 0, c->stream, reinterpret_cast<const R*>(accum_dev), (uint32_t)n_pixels, spp, d_rgb);
+  HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
+#define RTI_INSTANTIATE(R)                                                                                                                   \
+  template int build_image<R>(rt_context*, const rt_scene_desc&, const std::vector<TmpLink>&, int, const std::vector<int>&, SceneImage<R>&); \
+  template int render_accum_impl<R>(rt_context*, const rt_render_params&, void*, rt_stats*);                                                \
+  template int trace_batch_impl<R>(rt_context*, const rt_ray*, size_t, rt_hit*, uint64_t);                                                  \
+  template int pairs_kernel_impl<R>(rt_context*, int, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint32_t*, size_t, uint64_t, void*, \
+                                    size_t);                                                                                               \
+  template int resolve_impl<R>(rt_context*, const void*, size_t, uint32_t, uint8_t*);
+
+}  // namespace rti

@@ -1,0 +1,373 @@
+// C ABI of librtamd.so (declared in include/rtamd.h): context, scene validation and upload, dispatch to the
+// per-precision render code.  No kernels in this file.
+#include "context.h"
+
+namespace rti {
+thread_local std::string g_err;
+}
+using namespace rti;
+
+namespace {
+
+template <class R> void free_image(SceneImage<R>& im) {
+  if (im.d_blob) (void)hipFree(im.d_blob);
+  im = SceneImage<R>{};
+}
+
+void free_scene(rt_context* c) {
+  free_image(c->sf);
+  free_image(c->sd);
+  if (c->d_images) (void)hipFree(c->d_images);
+  c->d_images = nullptr;
+  for (uint8_t* p : c->d_image_bytes) (void)hipFree(p);
+  c->d_image_bytes.clear();
+  c->has_scene = false;
+}
+
+// ---- scene validation + threaded-link construction (host) ----
+struct LinkBuilder {
+  const rt_scene_desc& s;
+  std::vector<TmpLink> links;
+  std::vector<uint8_t> node_seen;
+  std::string err;
+  explicit LinkBuilder(const rt_scene_desc& sc) : s(sc), node_seen((size_t)std::max(0, sc.n_nodes), 0) {}
+
+  bool simple(int obj) const { return s.objects[obj].flags == 0u; }
+
+  int leaf(int obj, int next, int depth, int tree) {
+    TmpLink l{};
+    l.hit = LEAF_FLAG | (simple(obj) ? LEAF_SIMPLE : 0u) | (uint32_t)obj;
+    l.miss = next;
+    l.depth = depth; l.tree = tree;
+    links.push_back(l);
+    return (int)links.size() - 1;
+  }
+  int child(int c, int next, int depth, int tree) {
+    if (c >= 0) return node(c, next, depth, tree);
+    int obj = ~c;
+    if (obj < 0 || obj >= s.n_objects) { err = "BVH leaf references an object out of range"; return LINK_END; }
+    if (tree != 0 && (s.objects[obj].flags & RT_OBJ_SUB_BVH)) { err = "nested BVH inside a nested BVH is not supported"; return LINK_END; }
+    return leaf(obj, next, depth, tree);
+  }
+  // Emits the subtree of `n`; returns the index of its first link.  `next` is where traversal continues afterwards.
+  int node(int n, int next, int depth, int tree) {
+    if (!err.empty()) return LINK_END;
+    if (n < 0 || n >= s.n_nodes) { err = "BVH node index out of range"; return LINK_END; }
+    if (node_seen[n]) { err = "BVH node referenced twice (nodes must form trees)"; return LINK_END; }
+    if (depth > 512) { err = "BVH deeper than 512 levels"; return LINK_END; }
+    node_seen[n] = 1;
+    const rt_bvh_node& nd = s.nodes[n];
+    int me = (int)links.size();
+    links.push_back(TmpLink{});
+    int right_first, left_first;
+    // BVHNode::new gives a one-object node the same child twice (src/bvh.rs:38); the second test of a deterministic
+    // shape with t_max = its own t reproduces the first record, so it is dropped unless the object draws random numbers.
+    bool twin = nd.left < 0 && nd.left == nd.right && !(s.objects[std::min(std::max(~nd.left, 0), s.n_objects - 1)].flags & RT_OBJ_MEDIUM);
+    if (twin) {
+      left_first = child(nd.left, next, depth + 1, tree);
+    } else {
+      right_first = child(nd.right, next, depth + 1, tree);
+      left_first = child(nd.left, right_first, depth + 1, tree);
+    }
+    TmpLink& l = links[me];
+    for (int k = 0; k < 3; ++k) { l.bmin[k] = nd.bmin[k]; l.bmax[k] = nd.bmax[k]; }
+    l.hit = (uint32_t)left_first;
+    l.miss = next;
+    l.depth = depth; l.tree = tree;
+    return me;
+  }
+};
+
+int validate(const rt_scene_desc& s, std::string& err) {
+  auto bad = [&](const char* m) { err = m; return RT_E_INVALID; };
+  if (s.n_nodes <= 0 || s.n_objects <= 0 || s.n_shapes <= 0 || s.n_materials <= 0) return bad("scene has no nodes/objects/shapes/materials");
+  if (!s.nodes || !s.objects || !s.shapes || !s.materials) return bad("scene array pointer is NULL");
+  if (s.n_textures > 0 && !s.textures) return bad("textures pointer is NULL");
+  if (s.n_perlins > 0 && !s.perlins) return bad("perlins pointer is NULL");
+  if (s.n_images > 0 && !s.images) return bad("images pointer is NULL");
+  if ((uint32_t)s.n_objects > LEAF_INDEX_MASK) return bad("too many objects");
+  if (s.root_node < 0 || s.root_node >= s.n_nodes) return bad("root_node out of range");
+  for (int i = 0; i < s.n_textures; ++i) {
+    const rt_texture& t = s.textures[i];
+    switch (t.tag) {
+      case RT_TEX_SOLID: break;
+      case RT_TEX_CHECKER:
+        if (t.even < 0 || t.even >= s.n_textures || t.odd < 0 || t.odd >= s.n_textures) return bad("checker sub-texture out of range");
+        if (s.textures[t.even].tag == RT_TEX_CHECKER || s.textures[t.odd].tag == RT_TEX_CHECKER) {
+          err = "checker of checker textures is not supported";
+          return RT_E_UNSUPPORTED;
+        }
+        break;
+      case RT_TEX_NOISE:
+        if (t.perlin < 0 || t.perlin >= s.n_perlins) return bad("noise texture perlin index out of range");
+        break;
+      case RT_TEX_IMAGE:
+        if (t.image >= s.n_images) return bad("image texture index out of range");
+        break;
+      default: return bad("unknown texture tag");
+    }
+  }
+  for (int i = 0; i < s.n_images; ++i)
+    if (s.images[i].width <= 0 || s.images[i].height <= 0 || !s.images[i].rgb) return bad("bad image");
+  for (int i = 0; i < s.n_materials; ++i) {
+    const rt_material& m = s.materials[i];
+    if (m.tag < 0 || m.tag >= MAT_CLASSES) return bad("unknown material tag");
+    bool needs_tex = m.tag == RT_MAT_LAMBERTIAN || m.tag == RT_MAT_DIFFUSE_LIGHT || m.tag == RT_MAT_ISOTROPIC;
+    if (needs_tex && (m.texture < 0 || m.texture >= s.n_textures)) return bad("material texture out of range");
+  }
+  for (int i = 0; i < s.n_shapes; ++i) {
+    const rt_shape& sh = s.shapes[i];
+    if (sh.tag < RT_SHAPE_SPHERE || sh.tag > RT_SHAPE_BOX) return bad("unknown shape tag");
+    if (sh.material < 0 || sh.material >= s.n_materials) return bad("shape material out of range");
+  }
+  for (int i = 0; i < s.n_objects; ++i) {
+    const rt_object& o = s.objects[i];
+    if (o.flags & ~(RT_OBJ_TRANSLATE | RT_OBJ_ROTATE_Y | RT_OBJ_MEDIUM | RT_OBJ_SUB_BVH)) return bad("unknown object flag");
+    if (o.flags & RT_OBJ_SUB_BVH) {
+      if (o.geom < 0 || o.geom >= s.n_nodes) return bad("object sub-BVH root out of range");
+    } else if (o.geom < 0 || o.geom >= s.n_shapes) {
+      return bad("object shape out of range");
+    }
+    if ((o.flags & RT_OBJ_MEDIUM) && (o.medium_material < 0 || o.medium_material >= s.n_materials)) return bad("medium material out of range");
+  }
+  return RT_OK;
+}
+
+int check_render_params(const rt_context* c, const rt_render_params* p) {
+  if (!c) return fail(RT_E_INVALID, "context is NULL");
+  if (!p) return fail(RT_E_INVALID, "params is NULL");
+  if (!c->has_scene) return fail(RT_E_NO_SCENE, "no scene uploaded");
+  if (p->width < 2 || p->height < 2) return fail(RT_E_INVALID, "width and height must be at least 2 (the sample loop divides by W-1 and H-1)");
+  if ((uint64_t)p->width * p->height > 0x7FFFFFFFull) return fail(RT_E_INVALID, "image too large");
+  if (p->sample_end < p->sample_begin) return fail(RT_E_INVALID, "sample_end < sample_begin");
+  if (p->max_depth > kMaxDepth) return fail(RT_E_INVALID, "max_depth exceeds 4096");
+  if (p->precision != RT_PRECISION_F32 && p->precision != RT_PRECISION_F64) return fail(RT_E_INVALID, "unknown precision");
+  if (p->pipeline < RT_PIPELINE_AUTO || p->pipeline > RT_PIPELINE_SORTED) return fail(RT_E_INVALID, "unknown pipeline");
+  return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_err.c_str(); }
+const char* rt_version(void) { return "rtamd 0.1 (gfx950)"; }
+
+int rt_create(rt_context** out, int device) {
+  if (!out) return fail(RT_E_INVALID, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(RT_E_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+  if (device < 0 || device >= n) return fail(RT_E_NO_DEVICE, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  auto* c = new rt_context;
+  c->device = device;
+  c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  auto cleanup = [&](int code, const std::string& m) { rt_destroy(c); return fail(code, m); };
+  if (hipStreamCreate(&c->stream) != hipSuccess) return cleanup(RT_E_HIP, "hipStreamCreate failed");
+  for (auto& ev : c->ev)
+    if (hipEventCreate(&ev) != hipSuccess) return cleanup(RT_E_HIP, "hipEventCreate failed");
+  if (hipMalloc((void**)&c->d_counters, sizeof(uint32_t) * kCounterWords) != hipSuccess) return cleanup(RT_E_HIP, "hipMalloc counters failed");
+  if (hipMalloc((void**)&c->d_ray_count, sizeof(unsigned long long)) != hipSuccess) return cleanup(RT_E_HIP, "hipMalloc ray counter failed");
+  *out = c;
+  return RT_OK;
+}
+
+void rt_destroy(rt_context* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  free_scene(c);
+  if (c->ws) (void)hipFree(c->ws);
+  if (c->accum) (void)hipFree(c->accum);
+  if (c->d_counters) (void)hipFree(c->d_counters);
+  if (c->d_ray_count) (void)hipFree(c->d_ray_count);
+  for (auto& ev : c->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
+  if (!c || !s) return fail(RT_E_INVALID, "context or scene is NULL");
+  std::string err;
+  int rc = validate(*s, err);
+  if (rc) return fail(rc, "rt_upload_scene: " + err);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  free_scene(c);
+
+  // threaded links: the top-level tree first, then every nested tree
+  LinkBuilder lb(*s);
+  int root = lb.node(s->root_node, LINK_END, 0, 0);
+  std::vector<int> sub_root((size_t)s->n_objects, LINK_END);
+  int tree = 1;
+  for (int i = 0; i < s->n_objects && lb.err.empty(); ++i)
+    if (s->objects[i].flags & RT_OBJ_SUB_BVH) sub_root[i] = lb.node(s->objects[i].geom, LINK_END, 0, tree++);
+  if (!lb.err.empty()) return fail(lb.err.find("not supported") != std::string::npos ? RT_E_UNSUPPORTED : RT_E_INVALID, "rt_upload_scene: " + lb.err);
+  // sort by (nested?, depth): the first entries are the top levels of the main tree
+  std::vector<int> order(lb.links.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    const TmpLink &x = lb.links[a], &y = lb.links[b];
+    int kx = x.tree != 0, ky = y.tree != 0;
+    if (kx != ky) return kx < ky;
+    return x.depth < y.depth;
+  });
+  std::vector<int> new_index(order.size());
+  for (size_t i = 0; i < order.size(); ++i) new_index[order[i]] = (int)i;
+  std::vector<TmpLink> links(order.size());
+  for (size_t i = 0; i < order.size(); ++i) {
+    TmpLink l = lb.links[order[i]];
+    if (!(l.hit & LEAF_FLAG)) l.hit = (uint32_t)new_index[l.hit];
+    if (l.miss >= 0) l.miss = new_index[l.miss];
+    links[i] = l;
+  }
+  root = new_index[root];
+  for (int& r : sub_root)
+    if (r >= 0) r = new_index[r];
+
+  // images
+  if (s->n_images > 0) {
+    std::vector<DImage> host_images((size_t)s->n_images);
+    for (int i = 0; i < s->n_images; ++i) {
+      size_t bytes = (size_t)s->images[i].width * s->images[i].height * 3;
+      uint8_t* d = nullptr;
+      HIP_TRY(hipMalloc((void**)&d, bytes));
+      c->d_image_bytes.push_back(d);
+      HIP_TRY(hipMemcpy(d, s->images[i].rgb, bytes, hipMemcpyHostToDevice));
+      host_images[i] = DImage{d, s->images[i].width, s->images[i].height};
+    }
+    HIP_TRY(hipMalloc((void**)&c->d_images, sizeof(DImage) * host_images.size()));
+    HIP_TRY(hipMemcpy(c->d_images, host_images.data(), sizeof(DImage) * host_images.size(), hipMemcpyHostToDevice));
+  }
+  rc = build_image<float>(c, *s, links, root, sub_root, c->sf);
+  if (rc == RT_OK) rc = build_image<double>(c, *s, links, root, sub_root, c->sd);
+  if (rc != RT_OK) { free_scene(c); return rc; }
+  c->has_scene = true;
+  return RT_OK;
+}
+
+int rt_render_accum(rt_context* c, const rt_render_params* p, void* accum_dev, rt_stats* stats) {
+  int rc = check_render_params(c, p);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  if (p->precision == RT_PRECISION_F64) return render_accum_impl<double>(c, *p, accum_dev, stats);
+  return render_accum_impl<float>(c, *p, accum_dev, stats);
+}
+
+int rt_resolve(rt_context* c, const void* accum_dev, uint32_t width, uint32_t height, uint32_t spp, int precision, uint8_t* rgb8_out) {
+  if (!c || !rgb8_out) return fail(RT_E_INVALID, "context or output is NULL");
+  if (spp == 0) return fail(RT_E_INVALID, "samples_per_pixel is 0");
+  if (precision != RT_PRECISION_F32 && precision != RT_PRECISION_F64) return fail(RT_E_INVALID, "unknown precision");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t n = (size_t)width * height;
+  const size_t need = n * 4 * (precision == RT_PRECISION_F64 ? sizeof(double) : sizeof(float));
+  if (!accum_dev) {
+    if (!c->accum || c->accum_bytes < need) return fail(RT_E_INVALID, "the context holds no accumulation buffer of this size");
+    accum_dev = c->accum;
+  }
+  uint8_t* d_rgb = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_rgb, n * 3));
+  int rrc = precision == RT_PRECISION_F64 ? resolve_impl<double>(c, accum_dev, n, spp, d_rgb) : resolve_impl<float>(c, accum_dev, n, spp, d_rgb);
+  if (rrc) { (void)hipFree(d_rgb); return rrc; }
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess) e = hipMemcpyAsync(rgb8_out, d_rgb, n * 3, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_rgb);
+  if (e != hipSuccess) return fail(RT_E_HIP, std::string("rt_resolve: ") + hipGetErrorString(e));
+  return RT_OK;
+}
+
+int rt_read_accum(rt_context* c, const void* accum_dev, uint32_t width, uint32_t height, int precision, double* out) {
+  if (!c || !out) return fail(RT_E_INVALID, "context or output is NULL");
+  if (precision != RT_PRECISION_F32 && precision != RT_PRECISION_F64) return fail(RT_E_INVALID, "unknown precision");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t n = (size_t)width * height;
+  const size_t esz = precision == RT_PRECISION_F64 ? sizeof(double) : sizeof(float);
+  if (!accum_dev) {
+    if (!c->accum || c->accum_bytes < n * 4 * esz) return fail(RT_E_INVALID, "the context holds no accumulation buffer of this size");
+    accum_dev = c->accum;
+  }
+  std::vector<uint8_t> tmp(n * 4 * esz);
+  HIP_TRY(hipMemcpyAsync(tmp.data(), accum_dev, tmp.size(), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (size_t i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k)
+      out[i * 3 + k] = precision == RT_PRECISION_F64 ? reinterpret_cast<const double*>(tmp.data())[i * 4 + k]
+                                                      : (double)reinterpret_cast<const float*>(tmp.data())[i * 4 + k];
+  return RT_OK;
+}
+
+int rt_render(rt_context* c, const rt_render_params* p, uint8_t* rgb8_out, double* accum_out, rt_stats* stats) {
+  if (!rgb8_out && !accum_out) return fail(RT_E_INVALID, "no output buffer given");
+  auto t0 = std::chrono::steady_clock::now();
+  int rc = rt_render_accum(c, p, nullptr, stats);
+  if (rc) return rc;
+  if (p->sample_end == p->sample_begin && rgb8_out) return fail(RT_E_INVALID, "cannot resolve an image of zero samples");
+  if (rgb8_out) rc = rt_resolve(c, nullptr, p->width, p->height, p->sample_end - p->sample_begin, p->precision, rgb8_out);
+  if (rc == RT_OK && accum_out) rc = rt_read_accum(c, nullptr, p->width, p->height, p->precision, accum_out);
+  if (stats) stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return rc;
+}
+
+int rt_trace_batch(rt_context* c, const rt_ray* rays, size_t n, rt_hit* hits, int precision, uint64_t seed) {
+  if (!c) return fail(RT_E_INVALID, "context is NULL");
+  if (!c->has_scene) return fail(RT_E_NO_SCENE, "no scene uploaded");
+  if (n == 0) return RT_OK;
+  if (!rays || !hits) return fail(RT_E_INVALID, "rays or hits is NULL");
+  if (n > 0x7FFFFFFFull) return fail(RT_E_INVALID, "batch too large");
+  if (precision != RT_PRECISION_F32 && precision != RT_PRECISION_F64) return fail(RT_E_INVALID, "unknown precision");
+  HIP_TRY(hipSetDevice(c->device));
+  return precision == RT_PRECISION_F64 ? trace_batch_impl<double>(c, rays, n, hits, seed) : trace_batch_impl<float>(c, rays, n, hits, seed);
+}
+
+int rt_camera_rays(rt_context* c, uint32_t width, uint32_t height, const uint32_t* pixel, const uint32_t* sample, size_t n, uint64_t seed,
+                   int precision, rt_ray* out) {
+  if (!c) return fail(RT_E_INVALID, "context is NULL");
+  if (!c->has_scene) return fail(RT_E_NO_SCENE, "no scene uploaded");
+  if (n == 0) return RT_OK;
+  if (!pixel || !sample || !out) return fail(RT_E_INVALID, "NULL argument");
+  if (width < 2 || height < 2) return fail(RT_E_INVALID, "width and height must be at least 2");
+  for (size_t i = 0; i < n; ++i)
+    if (pixel[i] >= (uint64_t)width * height) return fail(RT_E_INVALID, "pixel index out of range");
+  HIP_TRY(hipSetDevice(c->device));
+  return precision == RT_PRECISION_F64 ? pairs_kernel_impl<double>(c, 0, width, height, 0, pixel, sample, n, seed, out, n * sizeof(rt_ray))
+                                       : pairs_kernel_impl<float>(c, 0, width, height, 0, pixel, sample, n, seed, out, n * sizeof(rt_ray));
+}
+
+int rt_sample_radiance(rt_context* c, uint32_t width, uint32_t height, uint32_t max_depth, const uint32_t* pixel, const uint32_t* sample, size_t n,
+                       uint64_t seed, int precision, double* out) {
+  if (!c) return fail(RT_E_INVALID, "context is NULL");
+  if (!c->has_scene) return fail(RT_E_NO_SCENE, "no scene uploaded");
+  if (n == 0) return RT_OK;
+  if (!pixel || !sample || !out) return fail(RT_E_INVALID, "NULL argument");
+  if (width < 2 || height < 2) return fail(RT_E_INVALID, "width and height must be at least 2");
+  for (size_t i = 0; i < n; ++i)
+    if (pixel[i] >= (uint64_t)width * height) return fail(RT_E_INVALID, "pixel index out of range");
+  HIP_TRY(hipSetDevice(c->device));
+  return precision == RT_PRECISION_F64
+             ? pairs_kernel_impl<double>(c, 1, width, height, max_depth, pixel, sample, n, seed, out, n * 4 * sizeof(double))
+             : pairs_kernel_impl<float>(c, 1, width, height, max_depth, pixel, sample, n, seed, out, n * 4 * sizeof(double));
+}
+
+int rt_sample_path(rt_context* c, uint32_t width, uint32_t height, uint32_t max_depth, const uint32_t* pixel, const uint32_t* sample, size_t n,
+                   uint64_t seed, int precision, uint32_t max_vertices, double* out) {
+  if (!c) return fail(RT_E_INVALID, "context is NULL");
+  if (!c->has_scene) return fail(RT_E_NO_SCENE, "no scene uploaded");
+  if (n == 0) return RT_OK;
+  if (!pixel || !sample || !out || max_vertices == 0) return fail(RT_E_INVALID, "NULL argument or max_vertices == 0");
+  if (width < 2 || height < 2) return fail(RT_E_INVALID, "width and height must be at least 2");
+  for (size_t i = 0; i < n; ++i)
+    if (pixel[i] >= (uint64_t)width * height) return fail(RT_E_INVALID, "pixel index out of range");
+  HIP_TRY(hipSetDevice(c->device));
+  size_t bytes = n * (4 + (size_t)max_vertices * 12) * sizeof(double);
+  return precision == RT_PRECISION_F64 ? pairs_kernel_impl<double>(c, 2, width, height, max_depth, pixel, sample, n, seed, out, bytes)
+                                       : pairs_kernel_impl<float>(c, 2, width, height, max_depth, pixel, sample, n, seed, out, bytes);
+}
+
+}  // extern "C"

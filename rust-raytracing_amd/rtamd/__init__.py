@@ -1,0 +1,349 @@
+"""ctypes binding of the MI355X path-tracing libraries.
+
+  librtamd.so       GPU hot path behind the C ABI of include/rtamd.h
+  librtamd_host.so  host side: scenes, camera, BVH build, image IO (include/rtamd_host.h)
+
+There is no CPU fallback anywhere in this package: importing it needs the two
+in-tree libraries (built by `make -C rust-raytracing_amd` or
+__graft_entry__.build()), and every compute call needs a HIP device.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+BUILD_DIR = os.path.join(os.path.dirname(_HERE), "_build")
+LIB_PATH = os.path.join(BUILD_DIR, "librtamd.so")
+HOST_LIB_PATH = os.path.join(BUILD_DIR, "librtamd_host.so")
+
+F32, F64 = 0, 1
+PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_SORTED = 0, 1, 2
+
+SCENES = {
+    "random": 0, "two-spheres": 1, "two-perlin-spheres": 2, "earth": 3, "simple-light": 4,
+    "cornell-box": 5, "cornell-smoke": 6, "final-scene": 7, "mega-spheres": 8,
+}
+
+# every symbol include/rtamd.h and include/rtamd_host.h declare
+ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_upload_scene", "rt_render_accum", "rt_resolve", "rt_read_accum", "rt_render",
+               "rt_trace_batch", "rt_camera_rays", "rt_sample_radiance", "rt_sample_path", "rt_last_error", "rt_version"]
+HOST_ABI_SYMBOLS = ["rth_scene_create", "rth_scene_destroy", "rth_scene_desc", "rth_scene_config", "rth_scene_from_name",
+                    "rth_scene_name", "rth_save_image", "rth_load_ppm", "rth_free", "rth_render_and_save", "rth_last_error"]
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("rtamd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32),
+                ("max_depth", C.c_uint32), ("precision", C.c_int32), ("pipeline", C.c_int32), ("samples_per_pass", C.c_uint32),
+                ("seed", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("camera_rays", C.c_uint64), ("seconds", C.c_double), ("bounce_kernel_ms", C.c_double),
+                ("bounce_kernel_launches", C.c_uint64), ("gen_kernel_ms", C.c_double), ("passes", C.c_uint64),
+                ("lds_bytes", C.c_uint32), ("scene_in_lds", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class SceneOpts(C.Structure):
+    _fields_ = [("scene", C.c_int32), ("width", C.c_int32), ("aspect", C.c_double), ("spp", C.c_int32), ("depth", C.c_int32),
+                ("aux_seed", C.c_uint64), ("bvh_seed", C.c_uint64), ("earth_rgb", C.c_void_p), ("earth_w", C.c_int32),
+                ("earth_h", C.c_int32), ("mega_grid", C.c_int32), ("pad", C.c_int32), ("earth_path", C.c_char_p)]
+
+
+class RenderConfig(C.Structure):
+    _fields_ = [("scene", SceneOpts), ("output", C.c_char_p), ("device", C.c_int32), ("precision", C.c_int32),
+                ("pipeline", C.c_int32), ("quiet", C.c_int32), ("seed", C.c_uint64)]
+
+
+class SceneDesc(C.Structure):
+    """Prefix of rt_scene_desc that Python inspects (camera, background, counts, array pointers)."""
+    _fields_ = [("camera", C.c_double * 24), ("bg_kind", C.c_int32), ("bg_pad", C.c_int32), ("bg_c0", C.c_double * 3),
+                ("bg_c1", C.c_double * 3), ("root_node", C.c_int32), ("n_nodes", C.c_int32), ("n_objects", C.c_int32),
+                ("n_shapes", C.c_int32), ("n_materials", C.c_int32), ("n_textures", C.c_int32), ("n_perlins", C.c_int32),
+                ("n_images", C.c_int32), ("nodes", C.c_void_p), ("objects", C.c_void_p), ("shapes", C.c_void_p),
+                ("materials", C.c_void_p), ("textures", C.c_void_p), ("perlins", C.c_void_p), ("images", C.c_void_p)]
+
+
+RAY_DTYPE = np.dtype([("o", "<f8", 3), ("d", "<f8", 3), ("time", "<f8"), ("tmin", "<f8"), ("tmax", "<f8"),
+                      ("pixel", "<u4"), ("sample", "<u4"), ("bounce", "<u4"), ("pad", "<u4")])
+HIT_DTYPE = np.dtype([("hit", "<i4"), ("obj", "<i4"), ("sub", "<i4"), ("side", "<i4"), ("material", "<i4"), ("front_face", "<i4"),
+                      ("t", "<f8"), ("p", "<f8", 3), ("n", "<f8", 3), ("u", "<f8"), ("v", "<f8")])
+NODE_DTYPE = np.dtype([("bmin", "<f8", 3), ("bmax", "<f8", 3), ("left", "<i4"), ("right", "<i4")])
+OBJECT_DTYPE = np.dtype([("flags", "<u4"), ("geom", "<i4"), ("medium_material", "<i4"), ("obj_id", "<i4"), ("sub_id", "<i4"),
+                         ("pad", "<i4"), ("offset", "<f8", 3), ("sin_theta", "<f8"), ("cos_theta", "<f8"), ("neg_inv_density", "<f8")])
+SHAPE_DTYPE = np.dtype([("tag", "<i4"), ("material", "<i4"), ("p", "<f8", 9)])
+MATERIAL_DTYPE = np.dtype([("tag", "<i4"), ("texture", "<i4"), ("albedo", "<f8", 3), ("fuzz", "<f8"), ("ir", "<f8")])
+TEXTURE_DTYPE = np.dtype([("tag", "<i4"), ("even", "<i4"), ("odd", "<i4"), ("perlin", "<i4"), ("image", "<i4"), ("pad", "<i4"),
+                          ("color", "<f8", 3), ("scale", "<f8")])
+
+_lib = None
+_host = None
+
+
+def load_libraries():
+    """Loads both libraries or raises: the product has no fallback when the HIP extension is missing."""
+    global _lib, _host
+    if _lib is not None:
+        return _lib, _host
+    for p in (LIB_PATH, HOST_LIB_PATH):
+        if not os.path.exists(p):
+            raise ImportError("%s is missing: build it with `make -C rust-raytracing_amd` (hipcc, gfx950)" % p)
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    H = C.CDLL(HOST_LIB_PATH)
+    vp = C.c_void_p
+    L.rt_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.rt_destroy.argtypes = [vp]
+    L.rt_destroy.restype = None
+    L.rt_upload_scene.argtypes = [vp, vp]
+    L.rt_render_accum.argtypes = [vp, C.POINTER(RenderParams), vp, C.POINTER(Stats)]
+    L.rt_resolve.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp]
+    L.rt_read_accum.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_int, vp]
+    L.rt_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
+    L.rt_trace_batch.argtypes = [vp, vp, C.c_size_t, vp, C.c_int, C.c_uint64]
+    L.rt_camera_rays.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, C.c_size_t, C.c_uint64, C.c_int, vp]
+    L.rt_sample_radiance.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, C.c_size_t, C.c_uint64, C.c_int, vp]
+    L.rt_sample_path.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, C.c_size_t, C.c_uint64, C.c_int, C.c_uint32, vp]
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_version.restype = C.c_char_p
+    H.rth_scene_create.restype = vp
+    H.rth_scene_create.argtypes = [C.POINTER(SceneOpts)]
+    H.rth_scene_destroy.argtypes = [vp]
+    H.rth_scene_destroy.restype = None
+    H.rth_scene_desc.restype = vp
+    H.rth_scene_desc.argtypes = [vp]
+    H.rth_scene_config.argtypes = [vp] + [C.POINTER(C.c_uint32)] * 4
+    H.rth_scene_config.restype = None
+    H.rth_scene_from_name.argtypes = [C.c_char_p]
+    H.rth_scene_name.restype = C.c_char_p
+    H.rth_scene_name.argtypes = [C.c_int]
+    H.rth_save_image.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
+    H.rth_load_ppm.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    H.rth_free.argtypes = [vp]
+    H.rth_free.restype = None
+    H.rth_render_and_save.argtypes = [C.POINTER(RenderConfig), C.POINTER(Stats)]
+    H.rth_last_error.restype = C.c_char_p
+    _lib, _host = L, H
+    return L, H
+
+
+def _check(rc):
+    if rc != 0:
+        raise RtError(rc, load_libraries()[0].rt_last_error().decode())
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Scene:
+    """SceneConfig::get_scene (src/scenes.rs:44-133) through the C++ host library."""
+
+    def __init__(self, name, width=0, aspect=0.0, spp=0, depth=0, aux_seed=1, bvh_seed=7, earth=None, earth_path=None, mega_grid=0):
+        _, H = load_libraries()
+        self.name = name
+        o = SceneOpts()
+        o.scene = SCENES[name] if isinstance(name, str) else int(name)
+        o.width, o.aspect, o.spp, o.depth = width, float(aspect), spp, depth
+        o.aux_seed, o.bvh_seed, o.mega_grid = aux_seed, bvh_seed, mega_grid
+        self._earth = None
+        if earth is not None:
+            self._earth = np.ascontiguousarray(earth, dtype=np.uint8)
+            o.earth_rgb = self._earth.ctypes.data
+            o.earth_h, o.earth_w = self._earth.shape[:2]
+        self._earth_path = earth_path.encode() if earth_path else None
+        o.earth_path = self._earth_path
+        self.h = H.rth_scene_create(C.byref(o))
+        if not self.h:
+            raise RuntimeError("rth_scene_create: " + H.rth_last_error().decode())
+        v = [C.c_uint32() for _ in range(4)]
+        H.rth_scene_config(self.h, *[C.byref(x) for x in v])
+        self.width, self.height, self.spp, self.depth = [x.value for x in v]
+        self.desc_ptr = H.rth_scene_desc(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None) and _host is not None:
+            _host.rth_scene_destroy(self.h)
+            self.h = None
+
+    @property
+    def desc(self):
+        return SceneDesc.from_address(self.desc_ptr)
+
+    def _array(self, ptr, n, dtype):
+        if not ptr or n <= 0:
+            return np.zeros(0, dtype=dtype)
+        buf = (C.c_uint8 * (n * dtype.itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype, count=n)
+
+    def nodes(self):
+        d = self.desc
+        return self._array(d.nodes, d.n_nodes, NODE_DTYPE)
+
+    def objects(self):
+        d = self.desc
+        return self._array(d.objects, d.n_objects, OBJECT_DTYPE)
+
+    def shapes(self):
+        d = self.desc
+        return self._array(d.shapes, d.n_shapes, SHAPE_DTYPE)
+
+    def materials(self):
+        d = self.desc
+        return self._array(d.materials, d.n_materials, MATERIAL_DTYPE)
+
+    def textures(self):
+        d = self.desc
+        return self._array(d.textures, d.n_textures, TEXTURE_DTYPE)
+
+    def camera(self):
+        return np.array(self.desc.camera[:], dtype=np.float64)
+
+
+class Context:
+    """One GPU.  Mirrors the lifetime of the thread pool in render() (src/render.rs:184)."""
+
+    def __init__(self, device=0):
+        L, _ = load_libraries()
+        h = C.c_void_p()
+        _check(L.rt_create(C.byref(h), device))
+        self.h = h
+        self.L = L
+        self.scene = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def upload(self, scene):
+        ptr = scene.desc_ptr if isinstance(scene, Scene) else scene
+        _check(self.L.rt_upload_scene(self.h, ptr))
+        self.scene = scene
+
+    def _params(self, width, height, s_begin, s_end, depth, precision, pipeline, samples_per_pass, seed):
+        sc = self.scene
+        p = RenderParams()
+        p.width = width or sc.width
+        p.height = height or sc.height
+        p.sample_begin, p.sample_end = s_begin, s_end
+        p.max_depth = depth if depth is not None else sc.depth
+        p.precision, p.pipeline, p.samples_per_pass, p.seed = precision, pipeline, samples_per_pass, seed
+        return p
+
+    def render(self, s_begin=0, s_end=None, precision=F32, pipeline=PIPELINE_AUTO, seed=0, samples_per_pass=0, depth=None, width=0,
+               height=0, want_accum=True, want_rgb=True):
+        """rt_render: returns (rgb8[H,W,3] or None, accum[H,W,3] float64 or None, stats dict)."""
+        if s_end is None:
+            s_end = self.scene.spp
+        p = self._params(width, height, s_begin, s_end, depth, precision, pipeline, samples_per_pass, seed)
+        rgb = np.zeros((p.height, p.width, 3), dtype=np.uint8) if want_rgb else None
+        acc = np.zeros((p.height, p.width, 3), dtype=np.float64) if want_accum else None
+        st = Stats()
+        _check(self.L.rt_render(self.h, C.byref(p), _p(rgb) if want_rgb else None, _p(acc) if want_accum else None, C.byref(st)))
+        return rgb, acc, st.as_dict()
+
+    def render_accum(self, accum_dev_ptr, s_begin, s_end, precision=F32, pipeline=PIPELINE_AUTO, seed=0, samples_per_pass=0, depth=None,
+                     width=0, height=0):
+        """rt_render_accum into a caller-owned DEVICE buffer (address as int) or the context's own (None)."""
+        p = self._params(width, height, s_begin, s_end, depth, precision, pipeline, samples_per_pass, seed)
+        st = Stats()
+        _check(self.L.rt_render_accum(self.h, C.byref(p), C.c_void_p(accum_dev_ptr) if accum_dev_ptr else None, C.byref(st)))
+        return st.as_dict()
+
+    def resolve(self, accum_dev_ptr, width, height, spp, precision=F32):
+        rgb = np.zeros((height, width, 3), dtype=np.uint8)
+        _check(self.L.rt_resolve(self.h, C.c_void_p(accum_dev_ptr) if accum_dev_ptr else None, width, height, spp, precision, _p(rgb)))
+        return rgb
+
+    def read_accum(self, accum_dev_ptr, width, height, precision=F32):
+        out = np.zeros((height, width, 3), dtype=np.float64)
+        _check(self.L.rt_read_accum(self.h, C.c_void_p(accum_dev_ptr) if accum_dev_ptr else None, width, height, precision, _p(out)))
+        return out
+
+    def trace_batch(self, rays, precision=F64, seed=0):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.zeros(rays.size, dtype=HIT_DTYPE)
+        _check(self.L.rt_trace_batch(self.h, _p(rays), rays.size, _p(hits), precision, seed))
+        return hits
+
+    def camera_rays(self, pixel, sample, seed=0, precision=F64, width=0, height=0):
+        pixel = np.ascontiguousarray(pixel, dtype=np.uint32)
+        sample = np.ascontiguousarray(sample, dtype=np.uint32)
+        out = np.zeros(pixel.size, dtype=RAY_DTYPE)
+        _check(self.L.rt_camera_rays(self.h, width or self.scene.width, height or self.scene.height, _p(pixel), _p(sample), pixel.size,
+                                     seed, precision, _p(out)))
+        return out
+
+    def sample_radiance(self, pixel, sample, seed=0, precision=F64, depth=None, width=0, height=0):
+        pixel = np.ascontiguousarray(pixel, dtype=np.uint32)
+        sample = np.ascontiguousarray(sample, dtype=np.uint32)
+        out = np.zeros((pixel.size, 4), dtype=np.float64)
+        _check(self.L.rt_sample_radiance(self.h, width or self.scene.width, height or self.scene.height,
+                                         depth if depth is not None else self.scene.depth, _p(pixel), _p(sample), pixel.size, seed,
+                                         precision, _p(out)))
+        return out
+
+    def sample_path(self, pixel, sample, seed=0, precision=F64, max_vertices=8, depth=None, width=0, height=0):
+        """Returns (radiance[n,4], vertices[n,max_vertices,12])."""
+        pixel = np.ascontiguousarray(pixel, dtype=np.uint32)
+        sample = np.ascontiguousarray(sample, dtype=np.uint32)
+        n = pixel.size
+        out = np.zeros(n * (4 + max_vertices * 12), dtype=np.float64)
+        _check(self.L.rt_sample_path(self.h, width or self.scene.width, height or self.scene.height,
+                                     depth if depth is not None else self.scene.depth, _p(pixel), _p(sample), n, seed, precision,
+                                     max_vertices, _p(out)))
+        return out[:n * 4].reshape(n, 4), out[n * 4:].reshape(n, max_vertices, 12)
+
+
+def save_image(path, rgb):
+    _, H = load_libraries()
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    rc = H.rth_save_image(path.encode(), _p(rgb), rgb.shape[1], rgb.shape[0])
+    if rc:
+        raise RuntimeError("rth_save_image: " + H.rth_last_error().decode())
+
+
+def load_ppm(path):
+    _, H = load_libraries()
+    ptr, w, h = C.c_void_p(), C.c_int32(), C.c_int32()
+    if H.rth_load_ppm(path.encode(), C.byref(ptr), C.byref(w), C.byref(h)):
+        raise RuntimeError("rth_load_ppm: " + H.rth_last_error().decode())
+    n = w.value * h.value * 3
+    out = np.frombuffer((C.c_uint8 * n).from_address(ptr.value), dtype=np.uint8).reshape(h.value, w.value, 3).copy()
+    H.rth_free(ptr)
+    return out
+
+
+def render_and_save(scene, output, device=0, precision=F32, pipeline=PIPELINE_AUTO, seed=0, quiet=True, **scene_kw):
+    """render_and_save (src/render.rs:278-284) through the host library."""
+    _, H = load_libraries()
+    cfg = RenderConfig()
+    cfg.scene.scene = SCENES[scene]
+    cfg.scene.width = scene_kw.get("width", 0)
+    cfg.scene.aspect = float(scene_kw.get("aspect", 0.0))
+    cfg.scene.spp = scene_kw.get("spp", 0)
+    cfg.scene.depth = scene_kw.get("depth", 0)
+    cfg.scene.aux_seed = scene_kw.get("aux_seed", 1)
+    cfg.scene.bvh_seed = scene_kw.get("bvh_seed", 7)
+    cfg.scene.mega_grid = scene_kw.get("mega_grid", 0)
+    ep = scene_kw.get("earth_path")
+    cfg.scene.earth_path = ep.encode() if ep else None
+    cfg.output = output.encode()
+    cfg.device, cfg.precision, cfg.pipeline, cfg.quiet, cfg.seed = device, precision, pipeline, 1 if quiet else 0, seed
+    st = Stats()
+    rc = H.rth_render_and_save(C.byref(cfg), C.byref(st))
+    if rc:
+        raise RuntimeError("rth_render_and_save: " + H.rth_last_error().decode())
+    return st.as_dict()

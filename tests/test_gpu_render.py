@@ -1,0 +1,151 @@
+"""Image parity: the HIP sample loop against the oracle's, on the same Philox streams.
+
+Because both sides draw the same random words, a GPU sample and an oracle sample follow the same path; the
+comparison is therefore far tighter than Monte-Carlo noise.  Stated tolerances:
+  f64 kernels : every per-sample radiance within 1e-9 relative (+1e-12 absolute) of the oracle;
+                per-pixel sums within 1e-9 relative of the oracle's sums.
+  f32 kernels : a small share of paths takes a different branch somewhere (an edge grazed in single precision),
+                so the bar is statistical: per-channel mean error <= 2e-3 relative and RMSE (of pixel means at the
+                test's sample count, linear radiance clamped to [0,1]) <= 0.02, next to a Monte-Carlo RMSE of ~0.1-0.3
+                at these sample counts.
+"""
+import numpy as np
+import pytest
+
+from scene_pairs import ALL_SCENES, make_pair
+
+pytestmark = pytest.mark.gpu
+
+SMALL = {  # width, spp for the full-frame comparisons (sized so the oracle finishes in seconds)
+    "random": (160, 4), "two-spheres": (200, 8), "two-perlin-spheres": (200, 8), "earth": (200, 8),
+    "simple-light": (200, 8), "cornell-box": (120, 8), "cornell-smoke": (120, 8), "final-scene": (100, 2),
+}
+
+
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_per_sample_radiance_f64(gpu, rtamd, oracle, earth_rgb, name):
+    hs, os_ = make_pair(rtamd, oracle, name, earth=earth_rgb)
+    gpu.upload(hs)
+    rng = np.random.default_rng(3)
+    n = 20_000 if name not in ("final-scene", "random") else 6_000
+    pixel = rng.integers(0, hs.width * hs.height, size=n).astype(np.uint32)
+    sample = rng.integers(0, 64, size=n).astype(np.uint32)
+    want = os_.sample_radiance(21, pixel, sample)
+    got = gpu.sample_radiance(pixel, sample, seed=21, precision=rtamd.F64)[:, :3]
+    err = np.abs(got - want) / (np.abs(want) + 1e-3)
+    bad = (err > 1e-9).any(axis=1)
+    assert bad.sum() == 0, "%s: %d of %d samples differ, worst %g" % (name, bad.sum(), n, err.max())
+
+
+@pytest.mark.parametrize("name", ALL_SCENES)
+@pytest.mark.parametrize("pipeline", ["fused", "sorted"])
+def test_frame_sums_f64(gpu, rtamd, oracle, earth_rgb, name, pipeline):
+    w, spp = SMALL[name]
+    hs, os_ = make_pair(rtamd, oracle, name, earth=earth_rgb, width=w, spp=spp)
+    gpu.upload(hs)
+    want, cnt, _ = os_.render(0, spp, seed=77)
+    pl = rtamd.PIPELINE_FUSED if pipeline == "fused" else rtamd.PIPELINE_SORTED
+    rgb, got, st = gpu.render(0, spp, precision=rtamd.F64, pipeline=pl, seed=77)
+    assert st["rays"] == cnt["rays"], "ray counts differ: gpu %d oracle %d" % (st["rays"], cnt["rays"])
+    assert st["camera_rays"] == cnt["camera_rays"]
+    err = np.abs(got - want) / (np.abs(want) + 1e-3)
+    assert err.max() < 1e-9, err.max()
+    assert np.array_equal(rgb, oracle.resolve(want, spp)) or (np.abs(rgb.astype(int) - oracle.resolve(want, spp).astype(int)).max() <= 1
+                                                              and (rgb != oracle.resolve(want, spp)).mean() < 1e-4)
+
+
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_frame_f32_within_tolerance(gpu, rtamd, oracle, earth_rgb, name):
+    w, spp = SMALL[name]
+    hs, os_ = make_pair(rtamd, oracle, name, earth=earth_rgb, width=w, spp=spp)
+    gpu.upload(hs)
+    want, cnt, _ = os_.render(0, spp, seed=5)
+    _, got, st = gpu.render(0, spp, precision=rtamd.F32, seed=5)
+    a = np.clip(got / spp, 0, 1)
+    b = np.clip(want / spp, 0, 1)
+    mean_err = np.abs(a.reshape(-1, 3).mean(0) - b.reshape(-1, 3).mean(0)) / b.reshape(-1, 3).mean(0)
+    rmse = np.sqrt(((a - b) ** 2).mean())
+    assert mean_err.max() < 2e-3, (name, mean_err)
+    assert rmse < 0.02, (name, rmse)
+    assert abs(st["rays"] - cnt["rays"]) / cnt["rays"] < 5e-3
+
+
+def test_sample_ranges_add_up(gpu, rtamd):
+    """Rendering [0,8) equals rendering [0,3) + [3,8): the stream is keyed by the global sample index (sample sharding)."""
+    hs = rtamd.Scene("cornell-box", width=96, spp=8)
+    gpu.upload(hs)
+    _, whole, _ = gpu.render(0, 8, precision=rtamd.F64, seed=9)
+    _, a, _ = gpu.render(0, 3, precision=rtamd.F64, seed=9)
+    _, b, _ = gpu.render(3, 8, precision=rtamd.F64, seed=9)
+    assert np.abs(whole - (a + b)).max() <= 1e-12 * max(1.0, whole.max())
+    # pass size must not matter either
+    _, c, _ = gpu.render(0, 8, precision=rtamd.F64, seed=9, samples_per_pass=3)
+    assert np.abs(whole - c).max() <= 1e-12 * max(1.0, whole.max())
+
+
+def test_furnace_energy_conservation(gpu, rtamd):
+    """Size-independent property at full 1080p: with max_depth = 1 only camera rays are traced, so the ray count is exactly
+    W*H*spp and the image is the directly visible emission / background."""
+    hs = rtamd.Scene("cornell-box", width=1920, aspect=16.0 / 9.0, spp=2)
+    gpu.upload(hs)
+    assert (hs.width, hs.height) == (1920, 1080)
+    _, acc, st = gpu.render(0, 2, precision=rtamd.F32, depth=1)
+    assert st["rays"] == 1920 * 1080 * 2 == st["camera_rays"]
+    # only the light (radiance 15 per sample) is visible at depth 1; everything else is black
+    vals = np.unique(np.round(acc.reshape(-1, 3)[:, 0], 3))
+    assert set(vals).issubset({0.0, 15.0, 30.0}), vals
+    assert (acc[..., 0] == 30.0).sum() > 1000
+
+
+def test_full_size_headline_config_properties(gpu, rtamd):
+    """cornell_box 1920x1080 at a few samples: rays/sample in the expected band, f32 and f64 agree in the mean,
+    two runs agree (same streams; float atomics may reorder additions)."""
+    hs = rtamd.Scene("cornell-box", width=1920, aspect=16.0 / 9.0, spp=4)
+    gpu.upload(hs)
+    _, a32, s32 = gpu.render(0, 4, precision=rtamd.F32, seed=1)
+    _, b32, _ = gpu.render(0, 4, precision=rtamd.F32, seed=1)
+    _, a64, s64 = gpu.render(0, 4, precision=rtamd.F64, seed=1)
+    assert 2.0 < s32["rays"] / s32["camera_rays"] < 8.0
+    assert np.abs(a32 - b32).max() <= 1e-4 * max(1.0, a32.max())
+    m32, m64 = np.clip(a32 / 4, 0, 1).mean(), np.clip(a64 / 4, 0, 1).mean()
+    assert abs(m32 - m64) / m64 < 2e-3
+    assert abs(s32["rays"] - s64["rays"]) / s64["rays"] < 5e-3
+
+
+def test_cornell_matches_reference_sample_render(gpu, rtamd):
+    """Statistical golden from the reference's own committed render cornell_box.png (600x600, scene defaults):
+    8x8 block means of clamped linear radiance (tests/golden/cornell_box_png_stats.json)."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "cornell_box_png_stats.json")) as f:
+        g = json.load(f)
+    hs = rtamd.Scene("cornell-box")
+    assert (hs.width, hs.height, hs.spp) == (600, 600, 200)
+    gpu.upload(hs)
+    rgb, acc, _ = gpu.render(0, 200, precision=rtamd.F32, seed=123)
+    lin = (rgb.astype(np.float64) / 256.0) ** 2  # same transform the fixture applied to the PNG
+    blocks = lin.reshape(8, 75, 8, 75, 3).mean(axis=(1, 3))
+    ref = np.array(g["block_means_linear"])
+    assert np.abs(lin.reshape(-1, 3).mean(0) - np.array(g["mean_linear"])).max() < 0.003
+    assert np.abs(blocks - ref).max() < 0.03
+    assert np.abs(rgb.reshape(-1, 3).mean(0) - np.array(g["mean_8bit"])).max() < 2.0
+
+
+def test_error_paths(rtamd):
+    """Every failure returns a code and a message; nothing falls back to a CPU path."""
+    ctx = rtamd.Context(0)
+    with pytest.raises(rtamd.RtError) as e:
+        ctx.scene = rtamd.Scene("cornell-box", width=32, spp=1)
+        ctx.render(0, 1)  # no scene uploaded
+    assert e.value.code == 4
+    ctx.upload(ctx.scene)
+    with pytest.raises(rtamd.RtError):
+        ctx.render(0, 1, width=1, height=1)
+    with pytest.raises(rtamd.RtError):
+        ctx.render(2, 1)
+    with pytest.raises(rtamd.RtError):
+        ctx.render(0, 1, precision=7)
+    with pytest.raises(rtamd.RtError):
+        rtamd.Context(4096)  # no such device
+    assert ctx.trace_batch(np.zeros(0, dtype=rtamd.RAY_DTYPE)).size == 0  # empty batch is fine
+    ctx.close()
