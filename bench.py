@@ -1,0 +1,200 @@
+"""Headline benchmark: Mrays/s on cornell_box 1920x1080, 1024 samples per pixel, depth 50, on 1..8 MI355X.
+
+One process per GPU.  A step is one complete render of the frame: every rank renders its share of the sample range
+[rank*S/N, (rank+1)*S/N) into its own accumulation buffer (scene already resident in HBM), the buffers are summed onto
+rank 0 with one reduce over RCCL, and rank 0 converts the sums to RGB8 and copies the image to the host.  Total work is
+fixed as N grows ("strong" scaling).  Rank 0 prints one JSON line.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "rust-raytracing_amd"))
+
+# Flop weights per event (adds and multiplies count 1; divide, sqrt and transcendentals count 1 each): the algorithmic
+# cost of the reference's own arithmetic, applied to event counts of the oracle on a sample of the same workload.
+FLOP_WEIGHTS = {
+    "aabb": 15, "sphere_miss": 23, "sphere_hit": 54, "moving_miss": 47, "moving_hit": 78, "rect_miss": 8, "rect_hit": 27,
+    "translate": 11, "rotate": 29, "medium": 12, "sc_lambert": 60, "sc_metal": 75, "sc_dielectric": 55, "sc_light": 0, "sc_iso": 40,
+    "tx_solid": 0, "tx_checker": 8, "tx_noise": 7 * 180 + 7, "tx_image": 10, "bg": 22,
+}
+VALU_PEAK_TFLOPS = 157.3   # MI355X FP32 vector peak
+VALU_PEAK_F64_TFLOPS = 78.6
+HBM_PEAK_GBS = 8000.0
+QUEUE_BYTES_PER_RAY = {"f32": 2 * 52, "f64": 2 * 96}  # one queue entry read + one written per ray (fused pipeline)
+
+
+def flops_per_ray(cnt):
+    return sum(FLOP_WEIGHTS[k] * cnt[k] for k in FLOP_WEIGHTS) / max(1, cnt["rays"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="cornell-box")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--aspect", type=float, default=16.0 / 9.0)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--pipeline", choices=["auto", "fused", "sorted"], default="auto")
+    ap.add_argument("--samples-per-pass", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the bounded CPU sample")
+    ap.add_argument("--save", default="", help="rank 0 writes the last image here (.png/.ppm)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import rtamd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path to time)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    prec = rtamd.F64 if args.precision == "f64" else rtamd.F32
+    pipe = {"auto": rtamd.PIPELINE_AUTO, "fused": rtamd.PIPELINE_FUSED, "sorted": rtamd.PIPELINE_SORTED}[args.pipeline]
+    tdtype = torch.float64 if prec == rtamd.F64 else torch.float32
+    earth = os.path.join(REPO, "rust-raytracing_amd", "assets", "earthmap.ppm")
+    scene = rtamd.Scene(args.scene, width=args.width, aspect=args.aspect, spp=args.spp, depth=args.depth, earth_path=earth)
+    W, H = scene.width, scene.height
+    ctx = rtamd.Context(local_rank)
+    ctx.upload(scene)
+    s0 = rank * args.spp // world
+    s1 = (rank + 1) * args.spp // world
+    accum = torch.zeros(H * W * 4, dtype=tdtype, device=dev)
+
+    def step():
+        accum.zero_()
+        torch.cuda.synchronize()  # the library renders on its own stream
+        st = ctx.render_accum(accum.data_ptr(), s0, s1, precision=prec, pipeline=pipe, samples_per_pass=args.samples_per_pass)
+        if dist is not None:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: W*H*4 values, once per frame
+            torch.cuda.synchronize()
+        rgb = ctx.resolve(accum.data_ptr(), W, H, args.spp, precision=prec) if rank == 0 else None
+        return st, rgb
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    stats = []
+    rgb = None
+    for _ in range(args.steps):
+        st, rgb = step()
+        stats.append(st)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    rays = float(sum(s["rays"] for s in stats))
+    bounce_ms = float(sum(s["bounce_kernel_ms"] for s in stats))
+    launches = float(sum(s["bounce_kernel_launches"] for s in stats))
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        r = torch.tensor([rays], dtype=torch.float64, device=dev)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rays_all = float(r.item())
+    else:
+        rays_all = rays
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/s cornell_box 1080p 1024spp" if (args.scene, args.width, args.spp) == ("cornell-box", 1920, 1024)
+            else "Mrays/s %s %dx%d %dspp" % (args.scene, W, H, args.spp),
+            "value": rays_all / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(1, args.steps),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": "%s %dx%d, %d spp, depth %d, samples sharded over ranks, one reduce to rank 0" % (args.scene, W, H, args.spp, args.depth),
+                       "pipeline": args.pipeline, "rays_per_step": rays_all / max(1, args.steps),
+                       "rays_per_camera_sample": rays_all / max(1, args.steps) / (W * H * args.spp),
+                       "lds_bytes": stats[-1]["lds_bytes"], "scene_in_lds": stats[-1]["scene_in_lds"]},
+        }
+        cpu = None
+        cnt = None
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(REPO, "tests"))
+            import oracle_lib  # the checker, used here only as the timed CPU baseline
+            threads = max(1, min(os.cpu_count() or 2, 16) - 1)  # num_cpus - 1 (src/render.rs:184), capped to this job's CPU share
+            earth_rgb = None
+            if args.scene in ("earth", "final-scene"):
+                earth_rgb = rtamd.load_ppm(earth)
+            osc = oracle_lib.OracleScene(args.scene, width=args.width, aspect=args.aspect, spp=args.spp, depth=args.depth, earth=earth_rgb)
+            _, cnt, secs = osc.render(0, args.cpu_spp, seed=0, threads=threads)
+            cpu = {"value": cnt["rays"] / secs / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+                   "sample": "same scene and frame, samples 0..%d of %d per pixel (%d rays), C++ f64 restatement of the reference with its "
+                             "row-block schedule; the Rust binary cannot be built here" % (args.cpu_spp, args.spp, cnt["rays"]),
+                   "seconds": secs, "host_cpus": os.cpu_count()}
+        out["cpu_baseline"] = cpu
+        # Roofline of the dominant kernel (the bounce kernel): algorithmic flops per ray x rays / summed kernel time.
+        fpr = flops_per_ray(cnt) if cnt else None
+        if fpr is None:
+            try:
+                with open(os.path.join(REPO, "profiles", "flops_per_ray.json")) as f:
+                    fpr = json.load(f).get(args.scene)
+            except OSError:
+                fpr = None
+        traffic = None
+        try:
+            with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f).get("%s_%s" % (args.scene, args.precision))
+        except OSError:
+            pass
+        if fpr is not None and bounce_ms > 0:
+            achieved = fpr * rays / (bounce_ms * 1e-3) / 1e12
+            peak = VALU_PEAK_F64_TFLOPS if args.precision == "f64" else VALU_PEAK_TFLOPS
+            qb = QUEUE_BYTES_PER_RAY[args.precision]
+            out["roofline"] = {
+                "bound": "valu", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                "flops_per_ray": fpr, "kernel": "k_bounce_fused", "avg_launch_ms": bounce_ms / max(1.0, launches), "launches": launches,
+                "note": "scene is LDS-resident; no dense contraction, so the vector ALU bounds this path, not MFMA",
+                "hbm": {"bound": "hbm", "achieved": qb * rays / (bounce_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": qb * rays / (bounce_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_ray": qb},
+            }
+        else:
+            out["roofline"] = None
+        print(json.dumps(out), flush=True)
+        if args.save and rgb is not None:
+            rtamd.save_image(args.save, rgb)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

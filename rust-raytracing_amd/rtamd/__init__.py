@@ -182,7 +182,7 @@ class Scene:
         if not ptr or n <= 0:
             return np.zeros(0, dtype=dtype)
         buf = (C.c_uint8 * (n * dtype.itemsize)).from_address(ptr)
-        return np.frombuffer(buf, dtype=dtype, count=n)
+        return np.frombuffer(buf, dtype=dtype, count=n).copy()  # the scene owns the memory; never hand out a view
 
     def nodes(self):
         d = self.desc

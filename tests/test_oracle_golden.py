@@ -1,0 +1,195 @@
+"""The CPU oracle against every known answer available for this path (no GPU needed).
+
+The reference's own test suite pins exactly one vector (src/aabb.rs:70-83); the rest are analytic identities of the
+reference's formulas, published test vectors of the generators it depends on, and statistics of its committed renders.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_aabb_reference_unit_test(oracle):
+    # src/aabb.rs:70-83: unit cube, o=(0.5,-0.5,0.5), d=(0,1,0): miss for (0,0.4), hit for (0,10)
+    assert not oracle.aabb_hit([0, 0, 0], [1, 1, 1], [0.5, -0.5, 0.5], [0, 1, 0], 0.0, 0.4)
+    assert oracle.aabb_hit([0, 0, 0], [1, 1, 1], [0.5, -0.5, 0.5], [0, 1, 0], 0.0, 10.0)
+
+
+def test_aabb_edge_semantics(oracle):
+    # t_max <= t_min rejects (src/aabb.rs:40): a ray that only touches the far face at exactly t_max... is a hit,
+    # a degenerate interval is a miss; direction component 0 gives +-inf / NaN and must not crash
+    assert oracle.aabb_hit([0, 0, 0], [1, 1, 1], [0.5, 0.5, -1], [0, 0, 1], 0.0, 1.5)
+    assert not oracle.aabb_hit([0, 0, 0], [1, 1, 1], [0.5, 0.5, -1], [0, 0, 1], 0.0, 1.0)  # enters at t=1: interval (1,1]
+    assert not oracle.aabb_hit([0, 0, 0], [1, 1, 1], [2, 0.5, 0.5], [0, 0, 1], 0.0, 10.0)  # parallel, outside the slab
+    assert oracle.aabb_hit([0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [0, 0, 1], 0.0, 10.0)   # parallel, inside
+    # inverted box (negative-radius sphere, src/sphere.rs:75-81) never passes
+    assert not oracle.aabb_hit([1, 1, 1], [0, 0, 0], [0.5, 0.5, -1], [0, 0, 1], 0.0, 10.0)
+
+
+@pytest.mark.parametrize("p,uv", [
+    ((1, 0, 0), (0.5, 0.5)), ((-1, 0.0, 0.0), (0.0, 0.5)), ((-1, 0, -0.0), (1.0, 0.5)), ((0, 1, 0), (0.5, 1.0)),
+    ((0, -1, 0), (0.5, 0.0)), ((0, 0, 1), (0.25, 0.5)), ((0, 0, -1), (0.75, 0.5))])
+def test_sphere_uv_known_answers(oracle, p, uv):
+    # src/sphere.rs:24-34, including the signed-zero behaviour of atan2 at x = -1
+    u, v = oracle.sphere_uv(p)
+    assert abs(u - uv[0]) < 1e-15 and abs(v - uv[1]) < 1e-15
+
+
+def test_sphere_hit_analytic(oracle):
+    h = oracle.shape_hit(0, [0, 0, 0, 1], (0, 0, -3), (0, 0, 1))
+    assert h["hit"] == 1 and h["t"] == 2.0 and tuple(h["p"]) == (0, 0, -1) and tuple(h["n"]) == (0, 0, -1) and h["front_face"] == 1
+    # from inside: second root, normal flipped against the ray, back face
+    h = oracle.shape_hit(0, [0, 0, 0, 1], (0, 0, 0), (0, 0, 2))
+    assert h["hit"] == 1 and h["t"] == 0.5 and h["front_face"] == 0 and tuple(h["n"]) == (0, 0, -1)
+    # t scales with 1/|d|: the reference never normalises directions
+    h = oracle.shape_hit(0, [0, 0, 0, 1], (0, 0, -3), (0, 0, 10))
+    assert abs(h["t"] - 0.2) < 1e-15
+    # t == t_max is accepted (src/sphere.rs:57), beyond is not
+    assert oracle.shape_hit(0, [0, 0, 0, 1], (0, 0, -3), (0, 0, 1), tmax=2.0)["hit"] == 1
+    assert oracle.shape_hit(0, [0, 0, 0, 1], (0, 0, -3), (0, 0, 1), tmax=1.999999)["hit"] == 0
+    # negative radius flips the outward normal (hollow-glass trick, src/scenes.rs:235-239)
+    h = oracle.shape_hit(0, [0, 0, 0, -1], (0, 0, -3), (0, 0, 1))
+    assert h["front_face"] == 0 and tuple(h["n"]) == (0, 0, -1)
+    assert oracle.shape_hit(0, [0, 0, 0, 1], (0, 2, -3), (0, 0, 1))["hit"] == 0
+
+
+def test_rect_hit_edges_closed(oracle):
+    # src/aarect.rs:88-107: closed interval in both in-plane coordinates, u,v normalised, normal +axis
+    prm = [0, 2, 0, 4, 5]  # x0 x1 y0 y1 k
+    h = oracle.shape_hit(1, prm, (1, 1, 0), (0, 0, 1))
+    assert h["hit"] == 1 and h["t"] == 5 and h["u"] == 0.5 and h["v"] == 0.25 and h["front_face"] == 0 and tuple(h["n"]) == (0, 0, -1)
+    assert oracle.shape_hit(1, prm, (2, 4, 0), (0, 0, 1))["hit"] == 1      # exactly on the corner
+    assert oracle.shape_hit(1, prm, (2.0000001, 4, 0), (0, 0, 1))["hit"] == 0
+    assert oracle.shape_hit(1, prm, (1, 1, 0), (1, 0, 0))["hit"] == 0      # parallel: t = inf
+    # A ray lying exactly in the plane gives t = 0/0 = NaN, and NaN passes every one of the reference's rejection tests
+    # (`t < t_min || t > t_max`, `x < x0 || ...` are all false): src/aarect.rs:89-97 reports a hit with t = NaN.
+    h = oracle.shape_hit(1, prm, (1, 1, 5), (1, 0, 0))
+    assert h["hit"] == 1 and math.isnan(h["t"])
+    h = oracle.shape_hit(2, [0, 2, 0, 4, 5], (1, 9, 1), (0, -1, 0))       # XZ from above: front face
+    assert h["hit"] == 1 and h["t"] == 4 and h["front_face"] == 1 and tuple(h["n"]) == (0, 1, 0)
+    h = oracle.shape_hit(3, [0, 2, 0, 4, 5], (0, 1, 1), (1, 0, 0))        # YZ
+    assert h["hit"] == 1 and h["t"] == 5 and h["u"] == 0.5 and h["v"] == 0.25
+
+
+def test_box_sides_and_tie_order(oracle):
+    box = [0, 0, 0, 1, 1, 1]
+    h = oracle.shape_hit(4, box, (0.5, 0.5, -2), (0, 0, 1))
+    assert h["hit"] == 1 and h["t"] == 2 and h["side"] == 1          # min-z face
+    h = oracle.shape_hit(4, box, (0.5, 0.5, 0.5), (0, 0, 1))
+    assert h["t"] == 0.5 and h["side"] == 0                           # from inside: max-z face
+    # a ray through the x=0,z=0 edge reaches two faces at the same t: the later one in the fixed order wins
+    h = oracle.shape_hit(4, box, (-1, 0.5, -1), (1, 0, 1))
+    assert h["t"] == 1 and h["side"] == 5
+
+
+def test_reflect_refract_schlick(oracle):
+    n = np.array([0.0, 1.0, 0.0])
+    v = np.array([1.0, -1.0, 0.0]) / math.sqrt(2)
+    assert np.allclose(oracle.reflect(v, n), [v[0], -v[1], 0], atol=1e-16)
+    assert np.allclose(oracle.refract(v, n, 1.0), v, atol=1e-15)       # no index change: straight through
+    r = oracle.refract(v, n, 1 / 1.5)
+    assert abs(np.linalg.norm(r) - 1) < 1e-15
+    assert abs(math.hypot(r[0], r[2]) - math.sin(math.pi / 4) / 1.5) < 1e-15   # Snell
+    r0 = ((1 - 1.5) / (1 + 1.5)) ** 2
+    assert oracle.schlick(1.0, 1.5) == r0
+    assert abs(oracle.schlick(0.0, 1.5) - 1.0) < 1e-15
+    assert abs(oracle.schlick(0.5, 1.5) - (r0 + (1 - r0) * 0.5 ** 5)) < 1e-16
+
+
+def test_color_to_rgb(oracle):
+    # src/color.rs:14-27: sqrt gamma, clamp to 0.999, *256 truncated; NaN -> 0
+    assert tuple(oracle.color_to_rgb([0, 0.25, 1.0], 1)) == (0, 128, 255)
+    assert tuple(oracle.color_to_rgb([100 * 0.25, 4 * 100.0, 100 * 0.9999], 100)) == (128, 255, 255)
+    assert tuple(oracle.color_to_rgb([float("nan"), -1.0, 1e-9], 1)) == (0, 0, 0)
+
+
+def test_divide_into_ranges(oracle):
+    # src/render.rs:247-271
+    assert oracle.divide_into_ranges(0, 4) == [(0, 0)]
+    assert oracle.divide_into_ranges(3, 8) == [(0, 1), (1, 2), (2, 3)]
+    assert oracle.divide_into_ranges(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    assert oracle.divide_into_ranges(1080, 15)[-1][1] == 1080
+
+
+def test_philox_published_vectors(oracle):
+    # Random123 known-answer vectors for philox4x32-10
+    assert [hex(x) for x in oracle.philox([0] * 4, [0] * 2)] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    assert [hex(x) for x in oracle.philox([0xffffffff] * 4, [0xffffffff] * 2)] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    assert [hex(x) for x in oracle.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])] == \
+        ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+def test_stream_layout(oracle):
+    # draw i = 64-bit word (i & 1) of block i/2; key (pixel, sample); counter (block, bounce | stage << 16, seed_lo, seed_hi)
+    seed, pixel, sample, bounce, stage = 0x1122334455667788, 12345, 67, 9, 2
+    words = oracle.stream_words(seed, pixel, sample, bounce, stage, 6)
+    for blk in range(3):
+        o = oracle.philox([blk, bounce | (stage << 16), seed & 0xffffffff, seed >> 32], [pixel, sample])
+        assert int(words[2 * blk]) == (int(o[1]) << 32) | int(o[0])
+        assert int(words[2 * blk + 1]) == (int(o[3]) << 32) | int(o[2])
+
+
+def test_pcg32_reference_stream(oracle):
+    # PCG-XSH-RR 64/32 of the PCG paper: state 0x853c49e6748fea9b / increment 0xda3e39cb94b95bdb is the canonical demo stream;
+    # here only determinism and the documented seeding recurrence can be checked offline (the rand_pcg crate is absent).
+    a, b = oracle.pcg32_words(2, 8), oracle.pcg32_words(2, 8)
+    assert np.array_equal(a, b) and len(set(a.tolist())) == 8
+    assert not np.array_equal(a, oracle.pcg32_words(3, 8))
+
+
+def test_scene_constants_match_reference_tables(oracle, earth_rgb):
+    # src/scenes.rs:44-133: width, aspect -> height (truncating), spp, depth per scene
+    expect = {"random": (400, 225, 100), "two-spheres": (400, 225, 100), "two-perlin-spheres": (400, 225, 100), "earth": (400, 225, 100),
+              "simple-light": (400, 225, 400), "cornell-box": (600, 600, 200), "cornell-smoke": (600, 600, 200), "final-scene": (800, 800, 10000)}
+    for name, (w, h, spp) in expect.items():
+        s = oracle.OracleScene(name, earth=earth_rgb if name in ("earth", "final-scene") else None)
+        assert (s.width, s.height, s.spp, s.depth) == (w, h, spp, 50), name
+    s = oracle.OracleScene("cornell-box", width=1920, aspect=16 / 9)
+    assert (s.width, s.height) == (1920, 1080)
+
+
+def test_random_scene_structure(oracle):
+    # src/scenes.rs:141-247: ground + <=484 small spheres + 3*22 duplicated big spheres + 4 leftovers
+    s = oracle.OracleScene("random")
+    assert 1 + 66 + 4 < s.n_objects <= 1 + 484 + 66 + 4
+    boxes = s.object_boxes()
+    assert np.allclose(boxes[0], [-1000, -2000, -1000, 1000, 0, 1000])
+    # the negative-radius sphere has an inverted box (min > max), carried over verbatim
+    inv = boxes[-2]
+    assert (inv[:3] > inv[3:]).all()
+
+
+def test_cornell_matches_reference_sample_render(oracle):
+    """Statistical golden: the oracle on the Cornell box (same camera and framing at 200x200, 64 samples) against block
+    statistics of the reference's committed 600x600, 200-sample cornell_box.png.  Pixel values are clamped like the PNG's
+    (0.999 before gamma); at 64 samples the clamp bias against 200 samples is below 1 %."""
+    with open(os.path.join(HERE, "golden", "cornell_box_png_stats.json")) as f:
+        g = json.load(f)
+    s = oracle.OracleScene("cornell-box", width=200, spp=64)
+    acc, cnt, _ = s.render(0, 64, seed=42)
+    lin = np.minimum(acc / 64, 0.999 ** 2)
+    mean = lin.reshape(-1, 3).mean(0)
+    ref = np.array(g["mean_linear"])
+    assert np.abs(mean - ref).max() / ref.max() < 0.03, (mean, ref)
+    blocks = lin.reshape(8, 25, 8, 25, 3).mean(axis=(1, 3))
+    assert np.abs(blocks - np.array(g["block_means_linear"])).max() < 0.05
+    assert 6.0 < cnt["rays"] / cnt["camera_rays"] < 7.5
+
+
+def test_oracle_sample_range_additivity(oracle):
+    s = oracle.OracleScene("cornell-box", width=48, spp=6)
+    whole, _, _ = s.render(0, 6, seed=3)
+    a, _, _ = s.render(0, 2, seed=3)
+    b, _, _ = s.render(2, 6, seed=3)
+    assert np.abs(whole - (a + b)).max() < 1e-12
+    # thread count and row partition do not change the result
+    c, _, _ = s.render(0, 6, seed=3, threads=1)
+    assert np.array_equal(whole, c)
+    px = np.array([5, 100, 2000], dtype=np.uint32)
+    sm = np.array([0, 3, 5], dtype=np.uint32)
+    rad = s.sample_radiance(3, px, sm)
+    assert rad.shape == (3, 3) and np.isfinite(rad).all()
