@@ -13,12 +13,10 @@
 #include <string>
 #include <vector>
 
-#include "device_scene.h"
+#include "kernel_table.h"
 #include "rtamd.h"
 
 namespace rti {
-using namespace rtd;
-
 extern thread_local std::string g_err;
 inline int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -33,14 +31,16 @@ inline int fail(int code, const std::string& msg) {
 constexpr uint32_t kBlock = 256;
 constexpr uint32_t kLdsAllMax = 64u * 1024u;  // stage the whole scene in LDS up to this size
 constexpr uint32_t kLdsTopMax = 32u * 1024u;  // otherwise stage this many bytes of top-level BVH links
-constexpr uint64_t kTargetPathsPerPass = 16ull << 20;
+constexpr uint64_t kTargetPathsPerPass = 64ull << 20;
 constexpr uint32_t kMaxDepth = 4096;
-constexpr uint32_t kCounterWords = (kMaxDepth + 2) + (kMaxDepth + 2) * 8;  // queue counts + per-bounce class counts
+constexpr uint32_t kSegments = 64;  // queue segments (a multiple of the 8 XCDs; at most the workgroup size)
+constexpr uint32_t kCounterWords = (kMaxDepth + 2) * kSegments * 9;  // per bounce and segment: queue count + 8 class counts
 
 template <class R> struct SceneImage {
   uint8_t* d_blob = nullptr;
   DeviceScene<R> dev{};
-  bool lds_all = false;
+  int preset = PRESET_ALL_TOP;
+  KernelTable<R> table{};
   uint32_t lds_bytes = 0;
 };
 
@@ -83,13 +83,14 @@ template <> inline SceneImage<double>& image_of<double>(rt_context* c) { return 
 inline uint32_t grid_for(const rt_context* c, uint64_t n, uint32_t blocks_per_cu) {
   uint64_t want = (n + kBlock - 1) / kBlock;
   uint64_t cap = (uint64_t)c->n_cus * blocks_per_cu;
-  return (uint32_t)std::max<uint64_t>(1, std::min(want, cap));
+  uint64_t g = std::max<uint64_t>(1, std::min(want, cap));
+  return (uint32_t)((g + kSegments - 1) / kSegments * kSegments);  // whole workgroups per queue segment
 }
 
 // Implemented once per precision (rt_f32.hip / rt_f64.hip).
 template <class R>
 int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink>& links, int root_link, const std::vector<int>& sub_root_of_object,
-                SceneImage<R>& im);
+                int preset, SceneImage<R>& im);
 template <class R> int render_accum_impl(rt_context* c, const rt_render_params& p, void* accum_dev, rt_stats* stats);
 template <class R> int trace_batch_impl(rt_context* c, const rt_ray* rays, size_t n, rt_hit* hits, uint64_t seed);
 template <class R>

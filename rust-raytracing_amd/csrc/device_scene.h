@@ -91,12 +91,68 @@ template <class R> struct DeviceScene {
   DBackground<R> background;
 };
 
-// What the hit / shade routines read.  LDS_ALL: every pointer addresses LDS.  Otherwise pointers address
-// global memory and `top` is the LDS copy of the first `n_top` links.
-template <class R, bool LDS_ALL> struct SceneView {
+// ---------------------------------------------------------------------------------------------
+// Kernel configuration: which parts of the scene grammar a kernel instantiation carries, and how it walks the tree.
+// A scene is rendered by the smallest preset that covers its contents; code for absent features is not compiled
+// in, which is what keeps the register count (and with it the waves per SIMD) of the common cases low.
+// ---------------------------------------------------------------------------------------------
+enum : uint32_t {
+  F_SPHERE = 1u << 0, F_MOVING = 1u << 1, F_RECT = 1u << 2, F_BOX = 1u << 3,
+  F_XFORM = 1u << 4,    // Translate / RotateY wrappers
+  F_MEDIUM = 1u << 5,   // ConstantMedium wrapper + Isotropic phase function
+  F_NESTED = 1u << 6,   // objects that are a BVH of their own
+  F_UV = 1u << 7,       // some texture reads (u, v): records carry them
+  F_CHECKER = 1u << 8, F_NOISE = 1u << 9, F_IMAGE = 1u << 10,
+  F_METAL = 1u << 11, F_DIELECTRIC = 1u << 12,
+  F_GRADIENT = 1u << 13,  // gradient background
+  F_ALL = (1u << 14) - 1u,
+};
+// WALK_UNIFORM: the tree is small (<= kUniformMaxLinks entries, stored in visiting order).  Every wave steps through the
+//   entries in order with a wave-uniform index, so entry, shape and object data arrive through scalar loads and live in
+//   scalar registers; a lane takes part in an entry only if its own traversal reaches it.
+// WALK_LANE: every lane follows its own hit/miss links; the first entries (top tree levels) or the whole scene sit in LDS.
+enum { WALK_UNIFORM = 0, WALK_LANE_LDS_ALL = 1, WALK_LANE_LDS_TOP = 2 };
+constexpr uint32_t kUniformMaxLinks = 96;
+
+template <uint32_t FEATURES, int WALK> struct Cfg {
+  static constexpr uint32_t F = FEATURES;
+  static constexpr int walk = WALK;
+  static constexpr bool has(uint32_t f) { return (FEATURES & f) != 0u; }
+};
+constexpr uint32_t P_BOXES = F_RECT | F_BOX | F_XFORM;                                  // cornell-box
+constexpr uint32_t P_SMOKE = P_BOXES | F_MEDIUM;                                        // cornell-smoke
+constexpr uint32_t P_SPHERES = F_SPHERE | F_RECT | F_UV | F_CHECKER | F_NOISE | F_IMAGE;  // two-spheres, perlin, earth, simple-light
+using CfgBoxes = Cfg<P_BOXES, WALK_UNIFORM>;
+using CfgSmoke = Cfg<P_SMOKE, WALK_UNIFORM>;
+using CfgSpheres = Cfg<P_SPHERES, WALK_UNIFORM>;
+using CfgAllLds = Cfg<F_ALL, WALK_LANE_LDS_ALL>;
+using CfgAllTop = Cfg<F_ALL, WALK_LANE_LDS_TOP>;
+enum { PRESET_BOXES = 0, PRESET_SMOKE = 1, PRESET_SPHERES = 2, PRESET_ALL_LDS = 3, PRESET_ALL_TOP = 4, PRESET_COUNT = 5 };
+
+// Read-only record at a wave-uniform address in global memory that no kernel writes (the scene blob): loaded through
+// the constant address space, i.e. by scalar loads into scalar registers.
+template <class T> RT_DEV T load_uniform(const T* p) {
+  static_assert(sizeof(T) % 16 == 0, "record size must be a multiple of 16 bytes");
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(4))) u32x4* const_ptr;
+  const_ptr q = (const_ptr)(uintptr_t)p;
+  union {
+    T t;
+    u32x4 v[sizeof(T) / 16];
+  } u;
+#pragma unroll
+  for (unsigned k = 0; k < sizeof(T) / 16; ++k) u.v[k] = q[k];
+  return u.t;
+}
+
+// What the hit / shade routines read.  `links`, `shapes`, `objects` are read with wave-uniform indices in WALK_UNIFORM
+// (global memory, scalar loads) and per lane otherwise; materials, textures and Perlin tables are always gathered per lane
+// and sit in LDS unless only the top links fit there.
+template <class R, class C> struct SceneView {
   const DLink<R>* links;
-  const DLink<R>* top;
+  const DLink<R>* top;  // WALK_LANE_LDS_TOP: LDS copy of the first n_top links
   uint32_t n_top;
+  uint32_t n_links;
   const DShape<R>* shapes;
   const DObject<R>* objects;
   const DMaterial<R>* materials;
@@ -105,12 +161,21 @@ template <class R, bool LDS_ALL> struct SceneView {
   const DImage* images;
 
   RT_DEV DLink<R> link(int i) const {
-    if constexpr (LDS_ALL) {
-      return links[i];
-    } else {
+    if constexpr (C::walk == WALK_LANE_LDS_TOP) {
       if ((uint32_t)i < n_top) return top[i];
-      return links[i];
     }
+    return links[i];
+  }
+  // Scene records addressed by an index that is the same in every lane (WALK_UNIFORM): fetched through the scalar
+  // data path, once per wave, whatever the lanes' execution mask is.
+  RT_DEV DLink<R> link_uniform(int i) const { return load_uniform(links + i); }
+  RT_DEV DShape<R> shape(int i) const {
+    if constexpr (C::walk == WALK_UNIFORM) return load_uniform(shapes + i);
+    else return shapes[i];
+  }
+  RT_DEV DObject<R> object(int i) const {
+    if constexpr (C::walk == WALK_UNIFORM) return load_uniform(objects + i);
+    else return objects[i];
   }
 };
 
@@ -121,27 +186,42 @@ RT_DEV void stage_to_lds(void* lds, const void* g, uint32_t bytes) {
   for (uint32_t i = threadIdx.x; i < bytes / 16u; i += blockDim.x) dst[i] = src[i];
 }
 
-template <class R, bool LDS_ALL> RT_DEV SceneView<R, LDS_ALL> make_view(const DeviceScene<R>& sc, uint8_t* lds) {
-  SceneView<R, LDS_ALL> v;
-  const uint8_t* base;
-  if constexpr (LDS_ALL) {
-    stage_to_lds(lds, sc.blob, sc.lay.total_bytes);
-    base = lds;
-    v.top = nullptr;
-    v.n_top = 0;
+// LDS bytes a workgroup needs for a configuration.
+template <class R, class C> inline uint32_t lds_bytes_for(const BlobLayout& lay, uint32_t lds_links) {
+  if (C::walk == WALK_UNIFORM) return lay.total_bytes - lay.materials_off;
+  if (C::walk == WALK_LANE_LDS_ALL) return lay.total_bytes;
+  return lds_links * (uint32_t)sizeof(DLink<R>);
+}
+
+template <class R, class C> RT_DEV SceneView<R, C> make_view(const DeviceScene<R>& sc, uint8_t* lds) {
+  SceneView<R, C> v;
+  const uint8_t* g = sc.blob;
+  const uint8_t* geom = g;   // base for links / shapes / objects
+  const uint8_t* shade = g;  // base for materials / textures / perlins ...
+  uint32_t shade_sub = 0;    // ... whose blob offsets are reduced by this much
+  v.top = nullptr;
+  v.n_top = 0;
+  if constexpr (C::walk == WALK_UNIFORM) {
+    stage_to_lds(lds, g + sc.lay.materials_off, sc.lay.total_bytes - sc.lay.materials_off);
+    shade = lds;
+    shade_sub = sc.lay.materials_off;
+  } else if constexpr (C::walk == WALK_LANE_LDS_ALL) {
+    stage_to_lds(lds, g, sc.lay.total_bytes);
+    geom = lds;
+    shade = lds;
   } else {
-    stage_to_lds(lds, sc.blob + sc.lay.links_off, sc.lds_links * (uint32_t)sizeof(DLink<R>));
-    base = sc.blob;
+    stage_to_lds(lds, g + sc.lay.links_off, sc.lds_links * (uint32_t)sizeof(DLink<R>));
     v.top = reinterpret_cast<const DLink<R>*>(lds);
     v.n_top = sc.lds_links;
   }
   __syncthreads();
-  v.links = reinterpret_cast<const DLink<R>*>(base + sc.lay.links_off);
-  v.shapes = reinterpret_cast<const DShape<R>*>(base + sc.lay.shapes_off);
-  v.objects = reinterpret_cast<const DObject<R>*>(base + sc.lay.objects_off);
-  v.materials = reinterpret_cast<const DMaterial<R>*>(base + sc.lay.materials_off);
-  v.textures = reinterpret_cast<const DTexture<R>*>(base + sc.lay.textures_off);
-  v.perlins = reinterpret_cast<const DPerlin<R>*>(base + sc.lay.perlins_off);
+  v.n_links = sc.lay.n_links;
+  v.links = reinterpret_cast<const DLink<R>*>(geom + sc.lay.links_off);
+  v.shapes = reinterpret_cast<const DShape<R>*>(geom + sc.lay.shapes_off);
+  v.objects = reinterpret_cast<const DObject<R>*>(geom + sc.lay.objects_off);
+  v.materials = reinterpret_cast<const DMaterial<R>*>(shade + (sc.lay.materials_off - shade_sub));
+  v.textures = reinterpret_cast<const DTexture<R>*>(shade + (sc.lay.textures_off - shade_sub));
+  v.perlins = reinterpret_cast<const DPerlin<R>*>(shade + (sc.lay.perlins_off - shade_sub));
   v.images = sc.images;
   return v;
 }

@@ -46,23 +46,23 @@ RT_DEV uint32_t sat_u32(float x) { return !(x > 0.0f) ? 0u : (x >= 4294967295.0f
 RT_DEV uint32_t sat_u32(double x) { return !(x > 0.0) ? 0u : (x >= 4294967295.0 ? 4294967295u : (uint32_t)x); }
 
 // Texture::value.  LEVEL 0 may be a checker whose two sub-textures are evaluated at LEVEL 1.
-template <class R, bool L, int LEVEL> RT_DEV V3<R> texture_value(const SceneView<R, L>& sv, int tex, R u, R v, V3<R> p) {
+template <class R, class C, int LEVEL> RT_DEV V3<R> texture_value(const SceneView<R, C>& sv, int tex, R u, R v, V3<R> p) {
   const DTexture<R> t = sv.textures[tex];
   switch (t.tag) {
     case TEX_SOLID: return V3<R>(t.color[0], t.color[1], t.color[2]);  // src/texture.rs:29-33
     case TEX_CHECKER: {                                               // src/texture.rs:54-63
-      if constexpr (LEVEL == 0) {
+      if constexpr (LEVEL == 0 && C::has(F_CHECKER)) {
         R sines = rt_sin((R)10 * p.x) * rt_sin((R)10 * p.y) * rt_sin((R)10 * p.z);
-        return texture_value<R, L, 1>(sv, sines < (R)0 ? t.odd : t.even, u, v, p);
+        return texture_value<R, C, 1>(sv, sines < (R)0 ? t.odd : t.even, u, v, p);
       } else {
         return V3<R>((R)0, (R)0, (R)0);
       }
     }
-    case TEX_NOISE: {  // src/texture.rs:79-85
+    case TEX_NOISE: if constexpr (C::has(F_NOISE)) {  // src/texture.rs:79-85
       R s = (R)1 + rt_sin(t.scale * p.z + (R)10 * perlin_turbulence(sv.perlins[t.perlin], p, 7));
       return (V3<R>((R)1, (R)1, (R)1) * V3<R>((R)0.5, (R)0.5, (R)0.5)) * V3<R>(s, s, s);
-    }
-    case TEX_IMAGE: {  // src/texture.rs:128-159
+    } break;
+    case TEX_IMAGE: if constexpr (C::has(F_IMAGE)) {  // src/texture.rs:128-159
       if (t.image < 0) return V3<R>((R)0, (R)1, (R)1);
       const DImage im = sv.images[t.image];
       R uc = rt_min(rt_max(u, (R)0), (R)1);
@@ -74,9 +74,10 @@ template <class R, bool L, int LEVEL> RT_DEV V3<R> texture_value(const SceneView
       const uint8_t* px = im.rgb + ((size_t)j * (size_t)im.width + i) * 3u;
       R color_scale = (R)1 / (R)255;
       return V3<R>(color_scale * (R)px[0], color_scale * (R)px[1], color_scale * (R)px[2]);
-    }
-    default: return V3<R>((R)0, (R)0, (R)0);
+    } break;
+    default: break;
   }
+  return V3<R>((R)0, (R)0, (R)0);
 }
 
 template <class R> RT_DEV R schlick_reflectance(R cosine, R ref_idx) {  // src/material.rs:104-109, powi(5) = x * (x^2)^2
@@ -90,10 +91,10 @@ template <class R> RT_DEV R schlick_reflectance(R cosine, R ref_idx) {  // src/m
 
 // material.emitted + material.scatter for a final hit record (src/render.rs:162-176).
 // Returns true when a scattered ray exists; `emitted` is always written.
-template <class R, bool L>
-RT_DEV bool shade_hit(const SceneView<R, L>& sv, const Ray<R>& ray_in, Rec<R>& rec, Stream& rng, V3<R>& emitted, V3<R>& attenuation,
+template <class R, class C>
+RT_DEV bool shade_hit(const SceneView<R, C>& sv, const Ray<R>& ray_in, Rec<R>& rec, Stream& rng, V3<R>& emitted, V3<R>& attenuation,
                       Ray<R>& scattered) {
-  rec.finish_uv();
+  if constexpr (C::has(F_UV)) rec.finish_uv();
   const DMaterial<R> m = sv.materials[rec.mat];
   emitted = V3<R>((R)0, (R)0, (R)0);
   scattered.o = rec.p;
@@ -103,16 +104,16 @@ RT_DEV bool shade_hit(const SceneView<R, L>& sv, const Ray<R>& ray_in, Rec<R>& r
       V3<R> dir = rec.n + random_unit_vector<R>(rng);
       if (near_zero(dir)) dir = rec.n;
       scattered.d = dir;
-      attenuation = texture_value<R, L, 0>(sv, m.texture, rec.u, rec.v, rec.p);
+      attenuation = texture_value<R, C, 0>(sv, m.texture, rec.u, rec.v, rec.p);
       return true;
     }
-    case MAT_METAL: {  // src/material.rs:75-90
+    case MAT_METAL: if constexpr (C::has(F_METAL)) {  // src/material.rs:75-90
       V3<R> reflected = reflect(unit_vector(ray_in.d), rec.n);
       scattered.d = reflected + m.fuzz * random_in_unit_sphere<R>(rng);
       attenuation = V3<R>(m.albedo[0], m.albedo[1], m.albedo[2]);
       return dot(scattered.d, rec.n) > (R)0;
-    }
-    case MAT_DIELECTRIC: {  // src/material.rs:113-139
+    } break;
+    case MAT_DIELECTRIC: if constexpr (C::has(F_DIELECTRIC)) {  // src/material.rs:113-139
       attenuation = V3<R>((R)1, (R)1, (R)1);
       R refraction_ratio = rec.front ? (R)1 / m.ir : m.ir;
       V3<R> unit_direction = unit_vector(ray_in.d);
@@ -123,22 +124,23 @@ RT_DEV bool shade_hit(const SceneView<R, L>& sv, const Ray<R>& ray_in, Rec<R>& r
       if (!do_reflect) do_reflect = schlick_reflectance(cos_theta, refraction_ratio) > gen01<R>(rng);  // `||` short-circuit
       scattered.d = do_reflect ? reflect(unit_direction, rec.n) : refract(unit_direction, rec.n, refraction_ratio);
       return true;
-    }
+    } break;
     case MAT_LIGHT: {  // src/material.rs:159-167
-      emitted = texture_value<R, L, 0>(sv, m.texture, rec.u, rec.v, rec.p);
+      emitted = texture_value<R, C, 0>(sv, m.texture, rec.u, rec.v, rec.p);
       return false;
     }
-    case MAT_ISOTROPIC: {  // src/material.rs:186-195
+    case MAT_ISOTROPIC: if constexpr (C::has(F_MEDIUM)) {  // src/material.rs:186-195
       scattered.d = random_in_unit_sphere<R>(rng);
-      attenuation = texture_value<R, L, 0>(sv, m.texture, rec.u, rec.v, rec.p);
+      attenuation = texture_value<R, C, 0>(sv, m.texture, rec.u, rec.v, rec.p);
       return true;
-    }
-    default: return false;
+    } break;
+    default: break;
   }
+  return false;
 }
 
-template <class R> RT_DEV V3<R> background_color(const DBackground<R>& bg, V3<R> direction) {  // src/color.rs:42-50
-  if (bg.kind == 0) return bg.c0;
+template <class R, class C> RT_DEV V3<R> background_color(const DBackground<R>& bg, V3<R> direction) {  // src/color.rs:42-50
+  if (bg.kind == 0 || !C::has(F_GRADIENT)) return bg.c0;
   V3<R> ud = unit_vector(direction);
   R t = (R)0.5 * (ud.y + (R)1);
   return ((R)1 - t) * bg.c1 + t * bg.c0;
@@ -155,7 +157,7 @@ RT_DEV Ray<R> primary_ray(const DCamera<R>& cam, uint32_t W, uint32_t H, uint32_
   R s = ((R)i + u_rand) / (R)(W - 1u);
   R t = ((R)j + v_rand) / (R)(H - 1u);
   V3<R> rd = cam.lens_radius * random_in_unit_disk<R>(rng);
-  V3<R> offset = (cam.u * V3<R>(rd.x, rd.x, rd.x)) + (cam.v * V3<R>(rd.y, rd.y, rd.y));
+  V3<R> offset = rd.x * cam.u + rd.y * cam.v;
   Ray<R> ray;
   ray.d = cam.lower_left_corner + s * cam.horizontal + t * cam.vertical - cam.origin - offset;
   ray.time = gen_range<R>(rng, cam.t_open, cam.t_close);

@@ -128,7 +128,7 @@ RT_DEV bool sphere_roots(V3<float> center, const Ray<float>& ray, float radius, 
 }
 
 // One axis-aligned rectangle.  AXIS is the constant axis; (A, B) the in-plane axes in the reference's (u, v) order.
-template <class R, int AXIS>
+template <class R, int AXIS, bool UV>
 RT_DEV bool rect_hit(R a0, R a1, R b0, R b1, R k, int material, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec) {  // src/aarect.rs:88-107
   constexpr int A = (AXIS == 0) ? 1 : 0;
   constexpr int B = (AXIS == 2) ? 1 : 2;
@@ -139,9 +139,11 @@ RT_DEV bool rect_hit(R a0, R a1, R b0, R b1, R k, int material, const Ray<R>& ra
   R a = o[A] + t * d[A];
   R b = o[B] + t * d[B];
   if (a < a0 || a > a1 || b < b0 || b > b1) return false;
-  rec.u = (a - a0) / (a1 - a0);
-  rec.v = (b - b0) / (b1 - b0);
-  rec.uv_lazy = 0;
+  if constexpr (UV) {  // no texture of the scene reads (u, v) otherwise
+    rec.u = (a - a0) / (a1 - a0);
+    rec.v = (b - b0) / (b1 - b0);
+    rec.uv_lazy = 0;
+  }
   rec.t = t;
   V3<R> outward(AXIS == 0 ? (R)1 : (R)0, AXIS == 1 ? (R)1 : (R)0, AXIS == 2 ? (R)1 : (R)0);
   rec.set_face_normal(ray.d, outward);
@@ -161,11 +163,12 @@ template <class R> RT_DEV V3<R> moving_center(const DShape<R>& s, R time) {  // 
 }
 
 // `self_side`: -2 when the ray does not start on this object, otherwise the side it starts on (-1 for one-sided shapes).
-template <class R> RT_DEV bool shape_hit(const DShape<R>& s, int leaf, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, int self_side) {
+template <class R, class C> RT_DEV bool shape_hit(const DShape<R>& s, int leaf, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, int self_side) {
+  constexpr bool UV = C::has(F_UV);
   bool hit = false;
   const bool self = Guard<R>::on && self_side != -2;
   switch (s.tag) {
-    case SH_SPHERE: {  // src/sphere.rs:38-73
+    case SH_SPHERE: if constexpr (C::has(F_SPHERE)) {  // src/sphere.rs:38-73
       V3<R> center(s.p[0], s.p[1], s.p[2]);
       R radius = s.p[3], root;
       if (sphere_roots(center, ray, radius, t_min, t_max, root, self)) {
@@ -175,13 +178,12 @@ template <class R> RT_DEV bool shape_hit(const DShape<R>& s, int leaf, const Ray
         rec.p = p;
         rec.set_face_normal(ray.d, outward);
         rec.mat = s.material;
-        rec.u = outward.x; rec.v = outward.y; rec.uw = outward.z; rec.uv_lazy = 1;
+        if constexpr (UV) { rec.u = outward.x; rec.v = outward.y; rec.uw = outward.z; rec.uv_lazy = 1; }
         rec.side = -1;
         hit = true;
       }
-      break;
-    }
-    case SH_MOVING: {  // src/moving_sphere.rs:44-72 (u, v are not written)
+    } break;
+    case SH_MOVING: if constexpr (C::has(F_MOVING)) {  // src/moving_sphere.rs:44-72 (u, v are not written)
       V3<R> center = moving_center(s, ray.time);
       R radius = s.p[6], root;
       if (sphere_roots(center, ray, radius, t_min, t_max, root, self)) {
@@ -194,112 +196,130 @@ template <class R> RT_DEV bool shape_hit(const DShape<R>& s, int leaf, const Ray
         rec.side = -1;
         hit = true;
       }
-      break;
-    }
-    case SH_RECT_XY: hit = !self && rect_hit<R, 2>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], s.material, ray, t_min, t_max, rec); if (hit) rec.side = -1; break;
-    case SH_RECT_XZ: hit = !self && rect_hit<R, 1>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], s.material, ray, t_min, t_max, rec); if (hit) rec.side = -1; break;
-    case SH_RECT_YZ: hit = !self && rect_hit<R, 0>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], s.material, ray, t_min, t_max, rec); if (hit) rec.side = -1; break;
-    case SH_BOX: {
+    } break;
+    case SH_RECT_XY: if constexpr (C::has(F_RECT)) { hit = !self && rect_hit<R, 2, UV>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], s.material, ray, t_min, t_max, rec); if (hit) rec.side = -1; } break;
+    case SH_RECT_XZ: if constexpr (C::has(F_RECT)) { hit = !self && rect_hit<R, 1, UV>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], s.material, ray, t_min, t_max, rec); if (hit) rec.side = -1; } break;
+    case SH_RECT_YZ: if constexpr (C::has(F_RECT)) { hit = !self && rect_hit<R, 0, UV>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], s.material, ray, t_min, t_max, rec); if (hit) rec.side = -1; } break;
+    case SH_BOX: if constexpr (C::has(F_BOX)) {
       // Six sides in the order of src/box_struct.rs:22-71, closest wins, a later side wins a tie
       // (src/hittable_list.rs:29-43: each success shrinks closest_so_far and overwrites the record).
       R lox = s.p[0], loy = s.p[1], loz = s.p[2], hix = s.p[3], hiy = s.p[4], hiz = s.p[5];
       R closest = t_max;
-      if (!(self && self_side == 0) && rect_hit<R, 2>(lox, hix, loy, hiy, hiz, s.material, ray, t_min, closest, rec)) { closest = rec.t; rec.side = 0; hit = true; }
-      if (!(self && self_side == 1) && rect_hit<R, 2>(lox, hix, loy, hiy, loz, s.material, ray, t_min, closest, rec)) { closest = rec.t; rec.side = 1; hit = true; }
-      if (!(self && self_side == 2) && rect_hit<R, 1>(lox, hix, loz, hiz, hiy, s.material, ray, t_min, closest, rec)) { closest = rec.t; rec.side = 2; hit = true; }
-      if (!(self && self_side == 3) && rect_hit<R, 1>(lox, hix, loz, hiz, loy, s.material, ray, t_min, closest, rec)) { closest = rec.t; rec.side = 3; hit = true; }
-      if (!(self && self_side == 4) && rect_hit<R, 0>(loy, hiy, loz, hiz, hix, s.material, ray, t_min, closest, rec)) { closest = rec.t; rec.side = 4; hit = true; }
-      if (!(self && self_side == 5) && rect_hit<R, 0>(loy, hiy, loz, hiz, lox, s.material, ray, t_min, closest, rec)) { closest = rec.t; rec.side = 5; hit = true; }
-      break;
-    }
+      if (!(self && self_side == 0) && rect_hit<R, 2, UV>(lox, hix, loy, hiy, hiz, s.material, ray, t_min, closest, rec)) { closest = rec.t; rec.side = 0; hit = true; }
+      if (!(self && self_side == 1) && rect_hit<R, 2, UV>(lox, hix, loy, hiy, loz, s.material, ray, t_min, closest, rec)) { closest = rec.t; rec.side = 1; hit = true; }
+      if (!(self && self_side == 2) && rect_hit<R, 1, UV>(lox, hix, loz, hiz, hiy, s.material, ray, t_min, closest, rec)) { closest = rec.t; rec.side = 2; hit = true; }
+      if (!(self && self_side == 3) && rect_hit<R, 1, UV>(lox, hix, loz, hiz, loy, s.material, ray, t_min, closest, rec)) { closest = rec.t; rec.side = 3; hit = true; }
+      if (!(self && self_side == 4) && rect_hit<R, 0, UV>(loy, hiy, loz, hiz, hix, s.material, ray, t_min, closest, rec)) { closest = rec.t; rec.side = 4; hit = true; }
+      if (!(self && self_side == 5) && rect_hit<R, 0, UV>(loy, hiy, loz, hiz, lox, s.material, ray, t_min, closest, rec)) { closest = rec.t; rec.side = 5; hit = true; }
+    } break;
     default: break;
   }
   if (hit) { rec.obj = s.obj_id; rec.sub = s.sub_id; rec.leaf = leaf; }
   return hit;
 }
 
-template <class R, bool L, int LEVEL>
-RT_DEV bool traverse(const SceneView<R, L>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org);
+template <class R, class C, int LEVEL>
+RT_DEV bool traverse_lane(const SceneView<R, C>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org);
 
 // [Translate(] [RotateY(] geometry [))] — the part of an object below an optional ConstantMedium.
-template <class R, bool L, int LEVEL>
-RT_DEV bool boundary_hit(const SceneView<R, L>& sv, const DObject<R>& ob, int obj_index, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec,
+template <class R, class C, int LEVEL>
+RT_DEV bool boundary_hit(const SceneView<R, C>& sv, const DObject<R>& ob, int obj_index, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec,
                          Stream& media, Origin org) {
   Ray<R> moved = ray;
-  if (ob.flags & OBJ_TRANSLATE) moved.o = ray.o - V3<R>(ob.offset[0], ob.offset[1], ob.offset[2]);  // src/hittable.rs:141
-  Ray<R> local = moved;
-  if (ob.flags & OBJ_ROTATE_Y) {  // src/hittable.rs:214-223 (ray time forced to 0)
-    local.o.x = ob.cos_theta * moved.o.x - ob.sin_theta * moved.o.z;
-    local.o.z = ob.sin_theta * moved.o.x + ob.cos_theta * moved.o.z;
-    local.d.x = ob.cos_theta * moved.d.x - ob.sin_theta * moved.d.z;
-    local.d.z = ob.sin_theta * moved.d.x + ob.cos_theta * moved.d.z;
-    local.time = (R)0;
+  Ray<R> local = ray;
+  if constexpr (C::has(F_XFORM)) {
+    if (ob.flags & OBJ_TRANSLATE) moved.o = ray.o - V3<R>(ob.offset[0], ob.offset[1], ob.offset[2]);  // src/hittable.rs:141
+    local = moved;
+    if (ob.flags & OBJ_ROTATE_Y) {  // src/hittable.rs:214-223 (ray time forced to 0)
+      local.o.x = ob.cos_theta * moved.o.x - ob.sin_theta * moved.o.z;
+      local.o.z = ob.sin_theta * moved.o.x + ob.cos_theta * moved.o.z;
+      local.d.x = ob.cos_theta * moved.d.x - ob.sin_theta * moved.d.z;
+      local.d.z = ob.sin_theta * moved.d.x + ob.cos_theta * moved.d.z;
+      local.time = (R)0;
+    }
   }
-  bool hit;
-  if (ob.flags & OBJ_SUB_BVH) {
-    if constexpr (LEVEL == 0) hit = traverse<R, L, 1>(sv, ob.sub_root, local, t_min, t_max, rec, media, org);
-    else hit = false;  // nested trees do not nest further (rejected at upload)
-  } else {
-    hit = shape_hit(sv.shapes[obj_index], obj_index, local, t_min, t_max, rec, org.leaf() == obj_index ? org.side() : -2);
+  bool hit = false;
+  bool nested = false;
+  if constexpr (C::has(F_NESTED) && LEVEL == 0) {  // nested trees do not nest further (rejected at upload)
+    if (ob.flags & OBJ_SUB_BVH) {
+      nested = true;
+      hit = traverse_lane<R, C, 1>(sv, ob.sub_root, local, t_min, t_max, rec, media, org);
+    }
   }
+  if (!nested) hit = shape_hit<R, C>(sv.shape(obj_index), obj_index, local, t_min, t_max, rec, org.leaf() == obj_index ? org.side() : -2);
   if (!hit) return false;
-  if (ob.flags & OBJ_ROTATE_Y) {  // src/hittable.rs:229-239
-    V3<R> p = rec.p, n = rec.n;
-    p.x = ob.cos_theta * rec.p.x + ob.sin_theta * rec.p.z;
-    p.z = -ob.sin_theta * rec.p.x + ob.cos_theta * rec.p.z;
-    n.x = ob.cos_theta * rec.n.x + ob.sin_theta * rec.n.z;
-    n.z = -ob.sin_theta * rec.n.x + ob.cos_theta * rec.n.z;
-    rec.p = p;
-    rec.set_face_normal(local.d, n);  // object-space direction against a world-space normal, as the reference does
-  }
-  if (ob.flags & OBJ_TRANSLATE) {  // src/hittable.rs:146-148
-    rec.p = rec.p + V3<R>(ob.offset[0], ob.offset[1], ob.offset[2]);
-    rec.set_face_normal(moved.d, rec.n);
+  if constexpr (C::has(F_XFORM)) {
+    if (ob.flags & OBJ_ROTATE_Y) {  // src/hittable.rs:229-239
+      V3<R> p = rec.p, n = rec.n;
+      p.x = ob.cos_theta * rec.p.x + ob.sin_theta * rec.p.z;
+      p.z = -ob.sin_theta * rec.p.x + ob.cos_theta * rec.p.z;
+      n.x = ob.cos_theta * rec.n.x + ob.sin_theta * rec.n.z;
+      n.z = -ob.sin_theta * rec.n.x + ob.cos_theta * rec.n.z;
+      rec.p = p;
+      rec.set_face_normal(local.d, n);  // object-space direction against a world-space normal, as the reference does
+    }
+    if (ob.flags & OBJ_TRANSLATE) {  // src/hittable.rs:146-148
+      rec.p = rec.p + V3<R>(ob.offset[0], ob.offset[1], ob.offset[2]);
+      rec.set_face_normal(moved.d, rec.n);
+    }
   }
   return true;
 }
 
-template <class R, bool L, int LEVEL>
-RT_DEV bool object_hit(const SceneView<R, L>& sv, int obj_index, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
-  const DObject<R> ob = sv.objects[obj_index];
-  if (!(ob.flags & OBJ_MEDIUM)) return boundary_hit<R, L, LEVEL>(sv, ob, obj_index, ray, t_min, t_max, rec, media, org);
-  // src/constant_medium.rs:41-111
-  const R inf = Lim<R>::inf();
-  Rec<R> rec1, rec2;
-  if (!boundary_hit<R, L, LEVEL>(sv, ob, obj_index, ray, -inf, inf, rec1, media, Origin())) return false;
-  R t_after = rec1.t + (R)0.0001;
-  if constexpr (Guard<R>::on) {
-    // f32: beyond |t| = 1024 the spacing of floats exceeds 0.0001 and the sum rounds back to rec1.t (a fog boundary of
-    // radius 5000 has t of that size); "strictly beyond the entry point" is what the reference's f64 sum means there.
-    if (!(t_after > rec1.t)) t_after = nextafterf(rec1.t, Lim<float>::inf());
+template <class R, class C, int LEVEL>
+RT_DEV bool object_hit(const SceneView<R, C>& sv, int obj_index, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
+  const DObject<R> ob = sv.object(obj_index);
+  if constexpr (C::has(F_MEDIUM)) {
+    if (ob.flags & OBJ_MEDIUM) {  // src/constant_medium.rs:41-111
+      const R inf = Lim<R>::inf();
+      Rec<R> rec1, rec2;
+      if (!boundary_hit<R, C, LEVEL>(sv, ob, obj_index, ray, -inf, inf, rec1, media, Origin())) return false;
+      R t_after = rec1.t + (R)0.0001;
+      if constexpr (Guard<R>::on) {
+        // f32: beyond |t| = 1024 the spacing of floats exceeds 0.0001 and the sum rounds back to rec1.t (a fog boundary of
+        // radius 5000 has t of that size); "strictly beyond the entry point" is what the reference's f64 sum means there.
+        if (!(t_after > rec1.t)) t_after = nextafterf(rec1.t, Lim<float>::inf());
+      }
+      if (!boundary_hit<R, C, LEVEL>(sv, ob, obj_index, ray, t_after, inf, rec2, media, Origin())) return false;
+      R t1 = rec1.t, t2 = rec2.t;
+      if (t1 < t_min) t1 = t_min;
+      if (t2 > t_max) t2 = t_max;
+      if (t1 >= t2) return false;
+      if (t1 < (R)0) t1 = (R)0;
+      R ray_length = length(ray.d);
+      R distance_inside_boundary = (t2 - t1) * ray_length;
+      R hit_distance = ob.neg_inv_density * gen_log01(media, (R)0);
+      if (hit_distance > distance_inside_boundary) return false;
+      rec.t = t1 + hit_distance / ray_length;
+      rec.p = ray.at(rec.t);
+      rec.n = V3<R>((R)1, (R)0, (R)0);
+      rec.front = 1;
+      rec.mat = ob.medium_material;  // u, v untouched
+      const DShape<R> ids = sv.shape(obj_index);
+      rec.obj = ids.obj_id;
+      rec.sub = ids.sub_id;
+      rec.side = -1;
+      rec.leaf = -1;
+      return true;
+    }
   }
-  if (!boundary_hit<R, L, LEVEL>(sv, ob, obj_index, ray, t_after, inf, rec2, media, Origin())) return false;
-  R t1 = rec1.t, t2 = rec2.t;
-  if (t1 < t_min) t1 = t_min;
-  if (t2 > t_max) t2 = t_max;
-  if (t1 >= t2) return false;
-  if (t1 < (R)0) t1 = (R)0;
-  R ray_length = length(ray.d);
-  R distance_inside_boundary = (t2 - t1) * ray_length;
-  R hit_distance = ob.neg_inv_density * gen_log01(media, (R)0);
-  if (hit_distance > distance_inside_boundary) return false;
-  rec.t = t1 + hit_distance / ray_length;
-  rec.p = ray.at(rec.t);
-  rec.n = V3<R>((R)1, (R)0, (R)0);
-  rec.front = 1;
-  rec.mat = ob.medium_material;  // u, v untouched
-  rec.obj = sv.shapes[obj_index].obj_id;
-  rec.sub = sv.shapes[obj_index].sub_id;
-  rec.side = -1;
-  rec.leaf = -1;
-  return true;
+  return boundary_hit<R, C, LEVEL>(sv, ob, obj_index, ray, t_min, t_max, rec, media, org);
 }
 
-// BVHNode::hit (src/bvh.rs:108-119) over the threaded list.  The running `closest` is the t_max every
-// node of the reference's recursion would receive: it starts as the caller's t_max and becomes rec.t
+template <class R, class C, int LEVEL>
+RT_DEV bool leaf_hit(const SceneView<R, C>& sv, uint32_t leaf_word, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
+  int obj = (int)(leaf_word & LEAF_INDEX_MASK);
+  if constexpr (C::has(F_XFORM) || C::has(F_MEDIUM) || C::has(F_NESTED)) {
+    if (!(leaf_word & LEAF_SIMPLE)) return object_hit<R, C, LEVEL>(sv, obj, ray, t_min, t_max, rec, media, org);
+  }
+  return shape_hit<R, C>(sv.shape(obj), obj, ray, t_min, t_max, rec, org.leaf() == obj ? org.side() : -2);
+}
+
+// BVHNode::hit (src/bvh.rs:108-119) over the threaded list, one traversal per lane.  The running `closest` is the
+// t_max every node of the reference's recursion would receive: it starts as the caller's t_max and becomes rec.t
 // after each accepted leaf, and nodes are visited in the reference's left-then-right order.
-template <class R, bool L, int LEVEL>
-RT_DEV bool traverse(const SceneView<R, L>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
+template <class R, class C, int LEVEL>
+RT_DEV bool traverse_lane(const SceneView<R, C>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
   V3<R> inv_d((R)1 / ray.d.x, (R)1 / ray.d.y, (R)1 / ray.d.z);
   R closest = t_max;
   bool any = false;
@@ -307,17 +327,47 @@ RT_DEV bool traverse(const SceneView<R, L>& sv, int start, const Ray<R>& ray, R 
   while (i >= 0) {
     const DLink<R> lk = sv.link(i);
     if (lk.hit & LEAF_FLAG) {
-      int obj = (int)(lk.hit & LEAF_INDEX_MASK);
-      bool h;
-      if (lk.hit & LEAF_SIMPLE) h = shape_hit(sv.shapes[obj], obj, ray, t_min, closest, rec, org.leaf() == obj ? org.side() : -2);
-      else h = object_hit<R, L, LEVEL>(sv, obj, ray, t_min, closest, rec, media, org);
-      if (h) { closest = rec.t; any = true; }
+      if (leaf_hit<R, C, LEVEL>(sv, lk.hit, ray, t_min, closest, rec, media, org)) { closest = rec.t; any = true; }
       i = lk.miss;
     } else {
       i = aabb_hit(lk, ray, inv_d, t_min, closest) ? (int)lk.hit : lk.miss;
     }
   }
   return any;
+}
+
+// The same walk for a small tree whose entries are stored in visiting order (an entry's hit link is the next index, its
+// miss link a larger one).  `cur` is the same in every lane of the wave, so the entry and whatever it refers to are
+// fetched once per wave by scalar loads; `want` is the entry this lane's own traversal needs next, and a lane only
+// acts on the entries it wants.  Lane by lane this performs exactly the tests of traverse_lane, in the same order.
+template <class R, class C>
+RT_DEV bool traverse_uniform(const SceneView<R, C>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
+  V3<R> inv_d((R)1 / ray.d.x, (R)1 / ray.d.y, (R)1 / ray.d.z);
+  R closest = t_max;
+  bool any = false;
+  const int end = (int)sv.n_links;
+  int want = start;
+  for (int cur = start; cur < end; ++cur) {
+    if (__ballot(want == cur) == 0ull) continue;
+    const DLink<R> lk = sv.link_uniform(cur);
+    const int miss = lk.miss < 0 ? end : lk.miss;
+    if (lk.hit & LEAF_FLAG) {
+      if (want == cur) {
+        if (leaf_hit<R, C, 0>(sv, lk.hit, ray, t_min, closest, rec, media, org)) { closest = rec.t; any = true; }
+        want = miss;
+      }
+    } else {
+      if (want == cur) want = aabb_hit(lk, ray, inv_d, t_min, closest) ? cur + 1 : miss;
+    }
+  }
+  return any;
+}
+
+// world.hit(ray, t_min, t_max, rec).  May be called from divergent code: lanes without a ray simply do not take part.
+template <class R, class C>
+RT_DEV bool closest_hit(const SceneView<R, C>& sv, int root, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
+  if constexpr (C::walk == WALK_UNIFORM) return traverse_uniform<R, C>(sv, root, ray, t_min, t_max, rec, media, org);
+  else return traverse_lane<R, C, 0>(sv, root, ray, t_min, t_max, rec, media, org);
 }
 
 }  // namespace rtd

@@ -1,0 +1,67 @@
+// One table of kernel launchers per (arithmetic type, preset).  Each table is instantiated in a translation unit of its
+// own (kt_*.hip) so the presets compile in parallel and the f64 ones can be built without multiply-add contraction.
+#pragma once
+#include "kernels.h"
+
+namespace rti {
+using namespace rtd;
+
+template <class R> struct KernelTable {
+  uint32_t (*lds_bytes)(const BlobLayout& lay, uint32_t lds_links);
+  void (*bounce_fused)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, PathQueue<R> in, PathQueue<R> out,
+                       uint32_t* counters, unsigned long long* ray_count, R* accum, uint32_t bounce);
+  void (*trace)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, PathQueue<R> in, HitQueue<R> hits,
+                uint32_t* counters, unsigned long long* ray_count, uint32_t* class_counters, uint32_t* class_index, uint32_t capacity, R* accum,
+                uint32_t bounce);
+  void (*shade)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, PathQueue<R> in, HitQueue<R> hits,
+                PathQueue<R> out, uint32_t* counters, const uint32_t* class_counters, const uint32_t* class_index, uint32_t capacity, R* accum,
+                uint32_t bounce);
+  void (*first_hit)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const RayIO* rays, uint32_t n, HitIO* hits, uint64_t seed);
+  void (*sample_radiance)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, uint32_t W, uint32_t H, uint32_t max_depth,
+                          const uint32_t* pixel, const uint32_t* sample, uint32_t n, uint64_t seed, double* out, double* path_out, uint32_t max_vertices);
+};
+
+constexpr uint32_t kBlockThreads = 256;
+
+template <class R, class C> KernelTable<R> make_table() {
+  KernelTable<R> t;
+  t.lds_bytes = [](const BlobLayout& lay, uint32_t lds_links) { return lds_bytes_for<R, C>(lay, lds_links); };
+  t.bounce_fused = [](uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, PathQueue<R> in, PathQueue<R> out,
+                      uint32_t* counters, unsigned long long* ray_count, R* accum, uint32_t bounce) {
+    hipLaunchKernelGGL((k_bounce_fused<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, in, out, counters, ray_count, accum, bounce);
+  };
+  t.trace = [](uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, PathQueue<R> in, HitQueue<R> hits,
+               uint32_t* counters, unsigned long long* ray_count, uint32_t* class_counters, uint32_t* class_index, uint32_t capacity, R* accum,
+               uint32_t bounce) {
+    hipLaunchKernelGGL((k_trace<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, in, hits, counters, ray_count, class_counters, class_index,
+                       capacity, accum, bounce);
+  };
+  t.shade = [](uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, PathQueue<R> in, HitQueue<R> hits,
+               PathQueue<R> out, uint32_t* counters, const uint32_t* class_counters, const uint32_t* class_index, uint32_t capacity, R* accum,
+               uint32_t bounce) {
+    hipLaunchKernelGGL((k_shade<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, in, hits, out, counters, class_counters, class_index,
+                       capacity, accum, bounce);
+  };
+  t.first_hit = [](uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const RayIO* rays, uint32_t n, HitIO* hits, uint64_t seed) {
+    hipLaunchKernelGGL((k_first_hit<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, rays, n, hits, seed);
+  };
+  t.sample_radiance = [](uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, uint32_t W, uint32_t H, uint32_t max_depth,
+                         const uint32_t* pixel, const uint32_t* sample, uint32_t n, uint64_t seed, double* out, double* path_out,
+                         uint32_t max_vertices) {
+    hipLaunchKernelGGL((k_sample_radiance<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, W, H, max_depth, pixel, sample, n, seed, out, path_out,
+                       max_vertices);
+  };
+  return t;
+}
+
+// Defined once per (R, preset) in kt_*.hip.
+template <class R, int PRESET> KernelTable<R> kernel_table();
+
+// Simple kernels without a preset (one instantiation per arithmetic type, in kt_*_common.hip).
+template <class R> void launch_gen_primary(uint32_t grid, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, PathQueue<R> out, uint32_t* counters);
+template <class R> void launch_resolve(uint32_t grid, hipStream_t st, const R* accum, uint32_t n_pixels, uint32_t spp, uint8_t* rgb);
+template <class R>
+void launch_camera_rays(uint32_t grid, hipStream_t st, const DeviceScene<R>& sc, uint32_t W, uint32_t H, const uint32_t* pixel, const uint32_t* sample,
+                        uint32_t n, uint64_t seed, RayIO* out);
+
+}  // namespace rti

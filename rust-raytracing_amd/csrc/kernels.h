@@ -83,7 +83,24 @@ struct FrameParams {
   uint32_t n_paths;      // n_pixels * samples in this pass
   uint32_t max_depth;
   uint64_t seed;
+  // The ray queue is split into n_seg independent segments of seg_cap slots.  Workgroup b serves segment b % n_seg only:
+  // it reads that segment's rays and appends the survivors to the same segment of the next queue, so every segment has a
+  // counter of its own (one shared counter saturates at under 10^8 returning atomics per second, far below the rate at
+  // which waves finish), and because workgroups b and b + 8 share an XCD a segment's rays stay in one XCD's L2.
+  uint32_t n_seg, seg_cap;
 };
+
+struct Segment {
+  uint32_t seg, first, step, origin;  // segment id, first local index of this workgroup, local stride, first slot of the segment
+};
+RT_DEV Segment segment_of_block(const FrameParams& fp) {
+  Segment g;
+  g.seg = blockIdx.x % fp.n_seg;
+  g.first = (blockIdx.x / fp.n_seg) * blockDim.x;
+  g.step = (gridDim.x / fp.n_seg) * blockDim.x;
+  g.origin = g.seg * fp.seg_cap;
+  return g;
+}
 
 // Primary rays for one pass: path index = sample_in_pass * n_pixels + pixel, so adjacent lanes hold adjacent pixels.
 template <class R>
@@ -100,35 +117,40 @@ __global__ __launch_bounds__(256) void k_gen_primary(DeviceScene<R> sc, FramePar
     st.org = Origin();
     store_path(out, i, st);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) counters[0] = fp.n_paths;
+  if (blockIdx.x == 0 && threadIdx.x < fp.n_seg) {  // path i sits in slot i: segment s starts with paths [s*seg_cap, (s+1)*seg_cap)
+    uint32_t lo = threadIdx.x * fp.seg_cap;
+    counters[threadIdx.x] = lo >= fp.n_paths ? 0u : (fp.n_paths - lo < fp.seg_cap ? fp.n_paths - lo : fp.seg_cap);
+  }
 }
 
 // One bounce for every queued ray: closest hit, miss shader or emitted + scatter, compaction into the next queue.
-template <class R, bool LDS_ALL>
+template <class R, class C>
 __global__ __launch_bounds__(256) void k_bounce_fused(DeviceScene<R> sc, FrameParams fp, PathQueue<R> in, PathQueue<R> out,
                                                       uint32_t* counters, unsigned long long* ray_count, R* accum, uint32_t bounce) {
   extern __shared__ __align__(16) uint8_t lds[];
-  const uint32_t n_in = counters[bounce];
-  if (blockIdx.x * blockDim.x >= n_in) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_count, (unsigned long long)n_in);
-  const SceneView<R, LDS_ALL> sv = make_view<R, LDS_ALL>(sc, lds);
+  const Segment sg = segment_of_block(fp);
+  const uint32_t n_in = counters[bounce * fp.n_seg + sg.seg];
+  if (sg.first >= n_in) return;
+  if (sg.first == 0 && threadIdx.x == 0) atomicAdd(ray_count, (unsigned long long)n_in);
+  const SceneView<R, C> sv = make_view<R, C>(sc, lds);
   const bool last = bounce + 1u >= fp.max_depth;  // ray_color(depth == 0) contributes nothing (src/render.rs:151-153)
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t base = blockIdx.x * blockDim.x; base < n_in; base += stride) {
-    uint32_t i = base + threadIdx.x;
+  uint32_t* const out_count = counters + (bounce + 1u) * fp.n_seg + sg.seg;
+  for (uint32_t base = sg.first; base < n_in; base += sg.step) {
+    const uint32_t j = base + threadIdx.x;
+    const uint32_t i = sg.origin + j;
     bool alive = false;
     PathState<R> st;
-    if (i < n_in) {
+    if (j < n_in) {
       st = load_path(in, i);
       Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
       Rec<R> rec;
-      if (!traverse<R, LDS_ALL, 0>(sv, sc.root_link, st.ray, (R)0.001, Lim<R>::inf(), rec, media, st.org)) {
-        add_radiance(accum, st.pixel, st.thr * background_color(sc.background, st.ray.d));
+      if (!closest_hit<R, C>(sv, sc.root_link, st.ray, (R)0.001, Lim<R>::inf(), rec, media, st.org)) {
+        add_radiance(accum, st.pixel, st.thr * background_color<R, C>(sc.background, st.ray.d));
       } else {
         Stream rng(fp.seed, st.pixel, st.sample, bounce, STAGE_SCATTER);
         V3<R> emitted, attenuation;
         Ray<R> scattered;
-        alive = shade_hit<R, LDS_ALL>(sv, st.ray, rec, rng, emitted, attenuation, scattered);
+        alive = shade_hit<R, C>(sv, st.ray, rec, rng, emitted, attenuation, scattered);
         add_radiance(accum, st.pixel, st.thr * emitted);
         if (alive) {
           st.thr = st.thr * attenuation;
@@ -138,7 +160,7 @@ __global__ __launch_bounds__(256) void k_bounce_fused(DeviceScene<R> sc, FramePa
       }
     }
     if (!last) {
-      uint32_t slot = compact_slot(alive, counters + bounce + 1u);
+      uint32_t slot = sg.origin + compact_slot(alive, out_count);
       if (alive) store_path(out, slot, st);
     }
   }
@@ -152,26 +174,27 @@ template <class R> struct HitQueue {
   R4* c;  // u, v, Origin bits of the surface hit, unused
 };
 
-// class_counters: MAT_CLASSES counters for this bounce; class_index[cls * capacity + k] = ray index.
-template <class R, bool LDS_ALL>
+// class_counters: 8 counters per segment for this bounce (MAT_CLASSES used); class_index[(cls * n_seg + seg) * seg_cap + k] = ray slot.
+template <class R, class C>
 __global__ __launch_bounds__(256) void k_trace(DeviceScene<R> sc, FrameParams fp, PathQueue<R> in, HitQueue<R> hits, uint32_t* counters,
                                                unsigned long long* ray_count, uint32_t* class_counters, uint32_t* class_index,
                                                uint32_t capacity, R* accum, uint32_t bounce) {
   extern __shared__ __align__(16) uint8_t lds[];
-  const uint32_t n_in = counters[bounce];
-  if (blockIdx.x * blockDim.x >= n_in) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_count, (unsigned long long)n_in);
-  const SceneView<R, LDS_ALL> sv = make_view<R, LDS_ALL>(sc, lds);
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t base = blockIdx.x * blockDim.x; base < n_in; base += stride) {
-    uint32_t i = base + threadIdx.x;
+  const Segment sg = segment_of_block(fp);
+  const uint32_t n_in = counters[bounce * fp.n_seg + sg.seg];
+  if (sg.first >= n_in) return;
+  if (sg.first == 0 && threadIdx.x == 0) atomicAdd(ray_count, (unsigned long long)n_in);
+  const SceneView<R, C> sv = make_view<R, C>(sc, lds);
+  for (uint32_t base = sg.first; base < n_in; base += sg.step) {
+    const uint32_t j = base + threadIdx.x;
+    const uint32_t i = sg.origin + j;
     int cls = -1;
-    if (i < n_in) {
+    if (j < n_in) {
       PathState<R> st = load_path(in, i);
       Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
       Rec<R> rec;
-      if (!traverse<R, LDS_ALL, 0>(sv, sc.root_link, st.ray, (R)0.001, Lim<R>::inf(), rec, media, st.org)) {
-        add_radiance(accum, st.pixel, st.thr * background_color(sc.background, st.ray.d));
+      if (!closest_hit<R, C>(sv, sc.root_link, st.ray, (R)0.001, Lim<R>::inf(), rec, media, st.org)) {
+        add_radiance(accum, st.pixel, st.thr * background_color<R, C>(sc.background, st.ray.d));
       } else {
         rec.finish_uv();
         cls = sv.materials[rec.mat].tag;
@@ -186,30 +209,31 @@ __global__ __launch_bounds__(256) void k_trace(DeviceScene<R> sc, FrameParams fp
     for (int k = 0; k < MAT_CLASSES; ++k) {
       bool mine = cls == k;
       if (__ballot(mine) != 0ull) {
-        uint32_t slot = compact_slot(mine, class_counters + k);
-        if (mine) class_index[(size_t)k * capacity + slot] = i;
+        uint32_t slot = compact_slot(mine, class_counters + sg.seg * 8u + k);
+        if (mine) class_index[((size_t)k * fp.n_seg + sg.seg) * fp.seg_cap + slot] = i;
       }
     }
   }
 }
 
-template <class R, bool LDS_ALL>
+template <class R, class C>
 __global__ __launch_bounds__(256) void k_shade(DeviceScene<R> sc, FrameParams fp, PathQueue<R> in, HitQueue<R> hits, PathQueue<R> out,
                                                uint32_t* counters, const uint32_t* class_counters, const uint32_t* class_index,
                                                uint32_t capacity, R* accum, uint32_t bounce) {
   extern __shared__ __align__(16) uint8_t lds[];
+  const Segment sg = segment_of_block(fp);
   uint32_t cls_end[MAT_CLASSES];
   uint32_t total = 0;
 #pragma unroll
   for (int k = 0; k < MAT_CLASSES; ++k) {
-    total += class_counters[k];
+    total += class_counters[sg.seg * 8u + k];
     cls_end[k] = total;
   }
-  if (blockIdx.x * blockDim.x >= total) return;
-  const SceneView<R, LDS_ALL> sv = make_view<R, LDS_ALL>(sc, lds);
+  if (sg.first >= total) return;
+  const SceneView<R, C> sv = make_view<R, C>(sc, lds);
   const bool last = bounce + 1u >= fp.max_depth;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t base = blockIdx.x * blockDim.x; base < total; base += stride) {
+  uint32_t* const out_count = counters + (bounce + 1u) * fp.n_seg + sg.seg;
+  for (uint32_t base = sg.first; base < total; base += sg.step) {
     uint32_t w = base + threadIdx.x;
     bool alive = false;
     PathState<R> st;
@@ -219,7 +243,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene<R> sc, FrameParams fp
 #pragma unroll
       for (int k = 0; k < MAT_CLASSES - 1; ++k)
         if (w >= cls_end[k]) { cls = (uint32_t)k + 1u; begin = cls_end[k]; }
-      uint32_t i = class_index[(size_t)cls * capacity + (w - begin)];
+      uint32_t i = class_index[((size_t)cls * fp.n_seg + sg.seg) * fp.seg_cap + (w - begin)];
       st = load_path(in, i);
       typename Vec4<R>::type a = hits.a[i], b = hits.b[i], c = hits.c[i];
       Rec<R> rec;
@@ -232,7 +256,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene<R> sc, FrameParams fp
       Stream rng(fp.seed, st.pixel, st.sample, bounce, STAGE_SCATTER);
       V3<R> emitted, attenuation;
       Ray<R> scattered;
-      alive = shade_hit<R, LDS_ALL>(sv, st.ray, rec, rng, emitted, attenuation, scattered);
+      alive = shade_hit<R, C>(sv, st.ray, rec, rng, emitted, attenuation, scattered);
       add_radiance(accum, st.pixel, st.thr * emitted);
       if (alive) {
         st.thr = st.thr * attenuation;
@@ -241,7 +265,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene<R> sc, FrameParams fp
       }
     }
     if (!last) {
-      uint32_t slot = compact_slot(alive, counters + bounce + 1u);
+      uint32_t slot = sg.origin + compact_slot(alive, out_count);
       if (alive) store_path(out, slot, st);
     }
   }
@@ -267,10 +291,11 @@ struct HitIO {  // = rt_hit
   double t, p[3], n[3], u, v;
 };
 
-template <class R, bool LDS_ALL>
+template <class R, class C>
 __global__ __launch_bounds__(256) void k_first_hit(DeviceScene<R> sc, const RayIO* rays, uint32_t n, HitIO* hits, uint64_t seed) {
   extern __shared__ __align__(16) uint8_t lds[];
-  const SceneView<R, LDS_ALL> sv = make_view<R, LDS_ALL>(sc, lds);
+  using CU = Cfg<C::F | F_UV, C::walk>;  // the inspection entry always reports (u, v)
+  const SceneView<R, CU> sv = make_view<R, CU>(sc, lds);
   uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     RayIO r = rays[i];
@@ -280,7 +305,7 @@ __global__ __launch_bounds__(256) void k_first_hit(DeviceScene<R> sc, const RayI
     ray.time = (R)r.time;
     Stream media(seed, r.pixel, r.sample, r.bounce, STAGE_MEDIA);
     Rec<R> rec;
-    bool h = traverse<R, LDS_ALL, 0>(sv, sc.root_link, ray, (R)r.tmin, (R)r.tmax, rec, media, Origin());
+    bool h = closest_hit<R, CU>(sv, sc.root_link, ray, (R)r.tmin, (R)r.tmax, rec, media, Origin());
     HitIO o;
     o.hit = h ? 1 : 0;
     if (h) {
@@ -314,12 +339,12 @@ __global__ void k_camera_rays(DeviceScene<R> sc, uint32_t W, uint32_t H, const u
 
 // Whole path in one thread (one lane follows one camera sample to termination).  Used to compare single samples
 // with a CPU evaluation; the render path uses the queue kernels above.
-template <class R, bool LDS_ALL>
+template <class R, class C>
 __global__ __launch_bounds__(256) void k_sample_radiance(DeviceScene<R> sc, uint32_t W, uint32_t H, uint32_t max_depth, const uint32_t* pixel,
                                                          const uint32_t* sample, uint32_t n, uint64_t seed, double* out, double* path_out,
                                                          uint32_t max_vertices) {
   extern __shared__ __align__(16) uint8_t lds[];
-  const SceneView<R, LDS_ALL> sv = make_view<R, LDS_ALL>(sc, lds);
+  const SceneView<R, C> sv = make_view<R, C>(sc, lds);
   uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     uint32_t px = pixel[i], sm = sample[i];
@@ -331,7 +356,7 @@ __global__ __launch_bounds__(256) void k_sample_radiance(DeviceScene<R> sc, uint
       ++n_rays;
       Stream media(seed, px, sm, bounce, STAGE_MEDIA);
       Rec<R> rec;
-      bool hit = traverse<R, LDS_ALL, 0>(sv, sc.root_link, ray, (R)0.001, Lim<R>::inf(), rec, media, org);
+      bool hit = closest_hit<R, C>(sv, sc.root_link, ray, (R)0.001, Lim<R>::inf(), rec, media, org);
       if (path_out && bounce < max_vertices) {  // one vertex = origin(3) direction(3) t obj sub material front hit
         double* v = path_out + ((size_t)i * max_vertices + bounce) * 12u;
         v[0] = (double)ray.o.x; v[1] = (double)ray.o.y; v[2] = (double)ray.o.z;
@@ -340,13 +365,13 @@ __global__ __launch_bounds__(256) void k_sample_radiance(DeviceScene<R> sc, uint
         v[9] = hit ? (double)rec.mat : -1.0; v[10] = hit ? (double)rec.front : 0.0; v[11] = hit ? 1.0 : 0.0;
       }
       if (!hit) {
-        sum = sum + thr * background_color(sc.background, ray.d);
+        sum = sum + thr * background_color<R, C>(sc.background, ray.d);
         break;
       }
       Stream rng(seed, px, sm, bounce, STAGE_SCATTER);
       V3<R> emitted, attenuation;
       Ray<R> scattered;
-      bool alive = shade_hit<R, LDS_ALL>(sv, ray, rec, rng, emitted, attenuation, scattered);
+      bool alive = shade_hit<R, C>(sv, ray, rec, rng, emitted, attenuation, scattered);
       sum = sum + thr * emitted;
       if (!alive) break;
       thr = thr * attenuation;

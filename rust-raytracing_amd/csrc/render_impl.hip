@@ -1,9 +1,19 @@
-// Host-side launch code for one arithmetic type; included by rt_f32.hip and rt_f64.hip, which instantiate it.
-#pragma once
+// Host-side render loop and test entry points for both arithmetic types.  The kernels themselves are reached through
+// the per-preset launcher tables of kernel_table.h.
 #include "context.h"
-#include "kernels.h"
+#include "kernel_table.h"
 
 namespace rti {
+
+template <class R> KernelTable<R> table_for(int preset) {
+  switch (preset) {
+    case PRESET_BOXES: return kernel_table<R, PRESET_BOXES>();
+    case PRESET_SMOKE: return kernel_table<R, PRESET_SMOKE>();
+    case PRESET_SPHERES: return kernel_table<R, PRESET_SPHERES>();
+    case PRESET_ALL_LDS: return kernel_table<R, PRESET_ALL_LDS>();
+    default: return kernel_table<R, PRESET_ALL_TOP>();
+  }
+}
 
 static_assert(sizeof(RayIO) == sizeof(rt_ray), "rt_ray layout");
 static_assert(sizeof(HitIO) == sizeof(rt_hit), "rt_hit layout");
@@ -26,7 +36,7 @@ template <> inline float round_up<float>(double x) {
 
 template <class R>
 int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink>& links, int root_link, const std::vector<int>& sub_root_of_object,
-                SceneImage<R>& im) {
+                int preset, SceneImage<R>& im) {
   BlobLayout lay{};
   uint32_t off = 0;
   lay.n_links = (uint32_t)links.size();
@@ -88,15 +98,17 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
   }
   HIP_TRY(hipMalloc((void**)&im.d_blob, blob.size()));
   HIP_TRY(hipMemcpy(im.d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
-  im.lds_all = lay.total_bytes <= kLdsAllMax;
+  if (preset == PRESET_ALL_LDS && lay.total_bytes > kLdsAllMax) preset = PRESET_ALL_TOP;  // the f64 image is larger than the f32 one
+  im.preset = preset;
+  im.table = table_for<R>(preset);
   DeviceScene<R>& d = im.dev;
   d.blob = im.d_blob;
   d.lay = lay;
   d.images = c->d_images;
   d.n_images = s.n_images;
   d.root_link = root_link;
-  d.lds_links = im.lds_all ? 0u : std::min<uint32_t>(lay.n_links, kLdsTopMax / (uint32_t)sizeof(DLink<R>));
-  im.lds_bytes = im.lds_all ? lay.total_bytes : d.lds_links * (uint32_t)sizeof(DLink<R>);
+  d.lds_links = preset == PRESET_ALL_TOP ? std::min<uint32_t>(lay.n_links, kLdsTopMax / (uint32_t)sizeof(DLink<R>)) : 0u;
+  im.lds_bytes = im.table.lds_bytes(lay, d.lds_links);
   auto v3 = [](const double* p) { return V3<R>((R)p[0], (R)p[1], (R)p[2]); };
   d.camera.origin = v3(s.camera.origin); d.camera.lower_left_corner = v3(s.camera.lower_left_corner);
   d.camera.horizontal = v3(s.camera.horizontal); d.camera.vertical = v3(s.camera.vertical);
@@ -140,7 +152,8 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
   uint32_t spp_pass = p.samples_per_pass ? p.samples_per_pass : (uint32_t)std::max<uint64_t>(1, kTargetPathsPerPass / n_pixels);
   spp_pass = std::max(1u, std::min(spp_pass, std::max(1u, n_samples)));
   if (n_pixels * spp_pass > 0x7FFFFFFFull) return fail(RT_E_INVALID, "width*height*samples_per_pass exceeds 2^31-1");
-  const uint64_t cap = n_pixels * spp_pass;
+  const uint32_t seg_cap = (uint32_t)(((n_pixels * spp_pass + kSegments - 1) / kSegments + 63) / 64 * 64);
+  const uint64_t cap = (uint64_t)seg_cap * kSegments;
   const bool sorted = p.pipeline == RT_PIPELINE_SORTED;
   // workspace: two ray queues (3 arrays each) [+ hit queue (3 arrays) + class index lists]
   size_t q_bytes = (size_t)cap * sizeof(R4);
@@ -166,46 +179,33 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
     class_index = reinterpret_cast<uint32_t*>(w);
   }
   uint32_t* counters = c->d_counters;
-  uint32_t* class_counters = c->d_counters + (kMaxDepth + 2);
+  uint32_t* class_counters = c->d_counters + (size_t)(kMaxDepth + 2) * kSegments;
   HIP_TRY(hipMemsetAsync(c->d_ray_count, 0, sizeof(unsigned long long), c->stream));
 
   double bounce_ms = 0.0, gen_ms = 0.0;
   uint64_t launches = 0, passes = 0;
-  const size_t counter_bytes = sizeof(uint32_t) * ((size_t)(kMaxDepth + 2) + (sorted ? (size_t)(p.max_depth + 1) * 8 : 0));
+  const size_t counter_bytes = sizeof(uint32_t) * (size_t)kSegments * ((size_t)(kMaxDepth + 2) + (sorted ? (size_t)(p.max_depth + 1) * 8 : 0));
   for (uint32_t s0 = p.sample_begin; s0 < p.sample_end; s0 += spp_pass) {
     uint32_t ns = std::min(spp_pass, p.sample_end - s0);
     FrameParams fp{};
     fp.width = p.width; fp.height = p.height; fp.n_pixels = (uint32_t)n_pixels;
     fp.sample_base = s0; fp.n_paths = (uint32_t)(n_pixels * ns); fp.max_depth = p.max_depth; fp.seed = p.seed;
-    HIP_TRY(hipMemsetAsync(counters, 0, sorted ? counter_bytes : sizeof(uint32_t) * (p.max_depth + 2), c->stream));
+    fp.n_seg = kSegments; fp.seg_cap = seg_cap;
+    HIP_TRY(hipMemsetAsync(counters, 0, sorted ? counter_bytes : sizeof(uint32_t) * (size_t)kSegments * (p.max_depth + 2), c->stream));
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    hipLaunchKernelGGL((k_gen_primary<R>), dim3(grid_for(c, fp.n_paths, 8)), dim3(kBlock), 0, c->stream, im.dev, fp, q[0], counters);
+    launch_gen_primary<R>(grid_for(c, fp.n_paths, 8), c->stream, im.dev, fp, q[0], counters);
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     const uint32_t grid = grid_for(c, fp.n_paths, 8);
     for (uint32_t b = 0; b < p.max_depth; ++b) {
       PathQueue<R>& in = q[b & 1u];
       PathQueue<R>& out = q[(b + 1u) & 1u];
       if (!sorted) {
-        if (im.lds_all)
-          hipLaunchKernelGGL((k_bounce_fused<R, true>), dim3(grid), dim3(kBlock), im.lds_bytes, c->stream, im.dev, fp, in, out, counters,
-                             c->d_ray_count, accum, b);
-        else
-          hipLaunchKernelGGL((k_bounce_fused<R, false>), dim3(grid), dim3(kBlock), im.lds_bytes, c->stream, im.dev, fp, in, out, counters,
-                             c->d_ray_count, accum, b);
+        im.table.bounce_fused(grid, im.lds_bytes, c->stream, im.dev, fp, in, out, counters, c->d_ray_count, accum, b);
         launches += 1;
       } else {
-        uint32_t* cc = class_counters + (size_t)b * 8;
-        if (im.lds_all) {
-          hipLaunchKernelGGL((k_trace<R, true>), dim3(grid), dim3(kBlock), im.lds_bytes, c->stream, im.dev, fp, in, hq, counters, c->d_ray_count,
-                             cc, class_index, (uint32_t)cap, accum, b);
-          hipLaunchKernelGGL((k_shade<R, true>), dim3(grid), dim3(kBlock), im.lds_bytes, c->stream, im.dev, fp, in, hq, out, counters, cc,
-                             class_index, (uint32_t)cap, accum, b);
-        } else {
-          hipLaunchKernelGGL((k_trace<R, false>), dim3(grid), dim3(kBlock), im.lds_bytes, c->stream, im.dev, fp, in, hq, counters, c->d_ray_count,
-                             cc, class_index, (uint32_t)cap, accum, b);
-          hipLaunchKernelGGL((k_shade<R, false>), dim3(grid), dim3(kBlock), im.lds_bytes, c->stream, im.dev, fp, in, hq, out, counters, cc,
-                             class_index, (uint32_t)cap, accum, b);
-        }
+        uint32_t* cc = class_counters + (size_t)b * 8 * kSegments;
+        im.table.trace(grid, im.lds_bytes, c->stream, im.dev, fp, in, hq, counters, c->d_ray_count, cc, class_index, (uint32_t)cap, accum, b);
+        im.table.shade(grid, im.lds_bytes, c->stream, im.dev, fp, in, hq, out, counters, cc, class_index, (uint32_t)cap, accum, b);
         launches += 2;
       }
     }
@@ -231,7 +231,7 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
     stats->gen_kernel_ms = gen_ms;
     stats->passes = passes;
     stats->lds_bytes = im.lds_bytes;
-    stats->scene_in_lds = im.lds_all ? 1u : 0u;
+    stats->scene_in_lds = (uint32_t)im.preset;
   }
   return RT_OK;
 }
@@ -247,8 +247,7 @@ template <class R> int trace_batch_impl(rt_context* c, const rt_ray* rays, size_
   do {
     if (hipMemcpyAsync(d_rays, rays, n * sizeof(RayIO), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(RT_E_HIP, "H2D rays failed"); break; }
     uint32_t grid = grid_for(c, n, 8);
-    if (im.lds_all) hipLaunchKernelGGL((k_first_hit<R, true>), dim3(grid), dim3(kBlock), im.lds_bytes, c->stream, im.dev, d_rays, (uint32_t)n, d_hits, seed);
-    else hipLaunchKernelGGL((k_first_hit<R, false>), dim3(grid), dim3(kBlock), im.lds_bytes, c->stream, im.dev, d_rays, (uint32_t)n, d_hits, seed);
+    im.table.first_hit(grid, im.lds_bytes, c->stream, im.dev, d_rays, (uint32_t)n, d_hits, seed);
     if (hipGetLastError() != hipSuccess) { rc = fail(RT_E_HIP, "k_first_hit launch failed"); break; }
     if (hipMemcpyAsync(hits, d_hits, n * sizeof(HitIO), hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail(RT_E_HIP, "D2H hits failed"); break; }
     if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(RT_E_HIP, "stream sync failed after k_first_hit"); break; }
@@ -276,20 +275,15 @@ int pairs_kernel_impl(rt_context* c, int which, uint32_t W, uint32_t H, uint32_t
       break;
     }
     if (which == 0) {
-      hipLaunchKernelGGL((k_camera_rays<R>), dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, im.dev, W, H, d_px, d_sm, (uint32_t)n,
-                         seed, reinterpret_cast<RayIO*>(d_out));
+      launch_camera_rays<R>((uint32_t)((n + kBlock - 1) / kBlock), c->stream, im.dev, W, H, d_px, d_sm, (uint32_t)n, seed, reinterpret_cast<RayIO*>(d_out));
     } else {
       uint32_t grid = grid_for(c, n, 8);
       // which == 2: `out` receives path vertices (max_vertices * 12 doubles per pair) after the 4 radiance doubles of every pair
       uint32_t max_vertices = which == 2 ? (uint32_t)((out_bytes / sizeof(double) / n - 4) / 12) : 0u;
       double* d_path = which == 2 ? reinterpret_cast<double*>(d_out) + n * 4 : nullptr;
       if (which == 2 && hipMemsetAsync(d_out, 0, out_bytes, c->stream) != hipSuccess) { rc = fail(RT_E_HIP, "memset failed"); break; }
-      if (im.lds_all)
-        hipLaunchKernelGGL((k_sample_radiance<R, true>), dim3(grid), dim3(kBlock), im.lds_bytes, c->stream, im.dev, W, H, max_depth, d_px, d_sm,
-                           (uint32_t)n, seed, reinterpret_cast<double*>(d_out), d_path, max_vertices);
-      else
-        hipLaunchKernelGGL((k_sample_radiance<R, false>), dim3(grid), dim3(kBlock), im.lds_bytes, c->stream, im.dev, W, H, max_depth, d_px, d_sm,
-                           (uint32_t)n, seed, reinterpret_cast<double*>(d_out), d_path, max_vertices);
+      im.table.sample_radiance(grid, im.lds_bytes, c->stream, im.dev, W, H, max_depth, d_px, d_sm, (uint32_t)n, seed, reinterpret_cast<double*>(d_out),
+                               d_path, max_vertices);
     }
     if (hipGetLastError() != hipSuccess) { rc = fail(RT_E_HIP, "kernel launch failed"); break; }
     if (hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail(RT_E_HIP, "D2H failed"); break; }
@@ -304,17 +298,21 @@ int pairs_kernel_impl(rt_context* c, int which, uint32_t W, uint32_t H, uint32_t
 
 template <class R> int resolve_impl(rt_context* c, const void* accum_dev, size_t n_pixels, uint32_t spp, uint8_t* d_rgb) {
   uint32_t grid = (uint32_t)((n_pixels + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL((k_resolve<R>), dim3(grid), dim3(kBlock), 0, c->stream, reinterpret_cast<const R*>(accum_dev), (uint32_t)n_pixels, spp, d_rgb);
+  launch_resolve<R>(grid, c->stream, reinterpret_cast<const R*>(accum_dev), (uint32_t)n_pixels, spp, d_rgb);
   HIP_TRY(hipGetLastError());
   return RT_OK;
 }
 
 #define RTI_INSTANTIATE(R)                                                                                                                   \
-  template int build_image<R>(rt_context*, const rt_scene_desc&, const std::vector<TmpLink>&, int, const std::vector<int>&, SceneImage<R>&); \
+  template int build_image<R>(rt_context*, const rt_scene_desc&, const std::vector<TmpLink>&, int, const std::vector<int>&, int, SceneImage<R>&); \
   template int render_accum_impl<R>(rt_context*, const rt_render_params&, void*, rt_stats*);                                                \
   template int trace_batch_impl<R>(rt_context*, const rt_ray*, size_t, rt_hit*, uint64_t);                                                  \
   template int pairs_kernel_impl<R>(rt_context*, int, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint32_t*, size_t, uint64_t, void*, \
                                     size_t);                                                                                               \
   template int resolve_impl<R>(rt_context*, const void*, size_t, uint32_t, uint8_t*);
+
+
+RTI_INSTANTIATE(float)
+RTI_INSTANTIATE(double)
 
 }  // namespace rti

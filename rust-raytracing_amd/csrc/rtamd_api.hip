@@ -1,5 +1,7 @@
 // C ABI of librtamd.so (declared in include/rtamd.h): context, scene validation and upload, dispatch to the
 // per-precision render code.  No kernels in this file.
+#include <cstdlib>
+
 #include "context.h"
 
 namespace rti {
@@ -208,15 +210,56 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   for (int i = 0; i < s->n_objects && lb.err.empty(); ++i)
     if (s->objects[i].flags & RT_OBJ_SUB_BVH) sub_root[i] = lb.node(s->objects[i].geom, LINK_END, 0, tree++);
   if (!lb.err.empty()) return fail(lb.err.find("not supported") != std::string::npos ? RT_E_UNSUPPORTED : RT_E_INVALID, "rt_upload_scene: " + lb.err);
-  // sort by (nested?, depth): the first entries are the top levels of the main tree
-  std::vector<int> order(lb.links.size());
-  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-    const TmpLink &x = lb.links[a], &y = lb.links[b];
-    int kx = x.tree != 0, ky = y.tree != 0;
-    if (kx != ky) return kx < ky;
-    return x.depth < y.depth;
-  });
+  // Which preset covers this scene?
+  uint32_t feat = 0;
+  bool has_nested = false;
+  for (int i = 0; i < s->n_objects; ++i) {
+    const rt_object& o = s->objects[i];
+    if (o.flags & (RT_OBJ_TRANSLATE | RT_OBJ_ROTATE_Y)) feat |= F_XFORM;
+    if (o.flags & RT_OBJ_MEDIUM) feat |= F_MEDIUM;
+    if (o.flags & RT_OBJ_SUB_BVH) { feat |= F_NESTED; has_nested = true; continue; }
+    switch (s->shapes[o.geom].tag) {
+      case RT_SHAPE_SPHERE: feat |= F_SPHERE; break;
+      case RT_SHAPE_MOVING_SPHERE: feat |= F_MOVING; break;
+      case RT_SHAPE_BOX: feat |= F_BOX; break;
+      default: feat |= F_RECT; break;
+    }
+  }
+  for (int i = 0; i < s->n_materials; ++i) {
+    if (s->materials[i].tag == RT_MAT_METAL) feat |= F_METAL;
+    if (s->materials[i].tag == RT_MAT_DIELECTRIC) feat |= F_DIELECTRIC;
+    if (s->materials[i].tag == RT_MAT_ISOTROPIC) feat |= F_MEDIUM;
+  }
+  for (int i = 0; i < s->n_textures; ++i) {
+    if (s->textures[i].tag == RT_TEX_CHECKER) feat |= F_CHECKER;
+    if (s->textures[i].tag == RT_TEX_NOISE) feat |= F_NOISE;
+    if (s->textures[i].tag == RT_TEX_IMAGE) feat |= F_IMAGE | F_UV;
+  }
+  if (s->background.kind == RT_BG_GRADIENT) feat |= F_GRADIENT;
+  const char* force = std::getenv("RTAMD_FORCE_GENERIC");
+  const bool small = lb.links.size() <= kUniformMaxLinks && !has_nested && !(force && force[0] == '1');
+  int preset = PRESET_ALL_LDS;  // build_image demotes to PRESET_ALL_TOP when the image does not fit in LDS
+  if (small && (feat & ~P_BOXES) == 0) preset = PRESET_BOXES;
+  else if (small && (feat & ~P_SMOKE) == 0) preset = PRESET_SMOKE;
+  else if (small && (feat & ~P_SPHERES) == 0) preset = PRESET_SPHERES;
+  const bool uniform = preset != PRESET_ALL_LDS;
+
+  std::vector<int> order;
+  if (uniform) {
+    // visiting order: follow the hit link of every box and the miss link of every leaf
+    for (int i = root; i >= 0; i = (lb.links[i].hit & LEAF_FLAG) ? lb.links[i].miss : (int)lb.links[i].hit) order.push_back(i);
+    if (order.size() != lb.links.size()) return fail(RT_E_INVALID, "rt_upload_scene: internal error while ordering links");
+  } else {
+    // sort by (nested?, depth): the first entries are the top levels of the main tree
+    order.resize(lb.links.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      const TmpLink &x = lb.links[a], &y = lb.links[b];
+      int kx = x.tree != 0, ky = y.tree != 0;
+      if (kx != ky) return kx < ky;
+      return x.depth < y.depth;
+    });
+  }
   std::vector<int> new_index(order.size());
   for (size_t i = 0; i < order.size(); ++i) new_index[order[i]] = (int)i;
   std::vector<TmpLink> links(order.size());
@@ -244,8 +287,8 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     HIP_TRY(hipMalloc((void**)&c->d_images, sizeof(DImage) * host_images.size()));
     HIP_TRY(hipMemcpy(c->d_images, host_images.data(), sizeof(DImage) * host_images.size(), hipMemcpyHostToDevice));
   }
-  rc = build_image<float>(c, *s, links, root, sub_root, c->sf);
-  if (rc == RT_OK) rc = build_image<double>(c, *s, links, root, sub_root, c->sd);
+  rc = build_image<float>(c, *s, links, root, sub_root, preset, c->sf);
+  if (rc == RT_OK) rc = build_image<double>(c, *s, links, root, sub_root, preset, c->sd);
   if (rc != RT_OK) { free_scene(c); return rc; }
   c->has_scene = true;
   return RT_OK;
