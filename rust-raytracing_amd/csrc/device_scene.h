@@ -155,6 +155,8 @@ template <class R, class C> struct SceneView {
   uint32_t n_links;
   const DShape<R>* shapes;
   const DObject<R>* objects;
+  const DShape<R>* shapes_lane;    // the same records where a lane gathers them with an index of its own (LDS in WALK_UNIFORM)
+  const DObject<R>* objects_lane;
   const DMaterial<R>* materials;
   const DTexture<R>* textures;
   const DPerlin<R>* perlins;
@@ -188,7 +190,7 @@ RT_DEV void stage_to_lds(void* lds, const void* g, uint32_t bytes) {
 
 // LDS bytes a workgroup needs for a configuration.
 template <class R, class C> inline uint32_t lds_bytes_for(const BlobLayout& lay, uint32_t lds_links) {
-  if (C::walk == WALK_UNIFORM) return lay.total_bytes - lay.materials_off;
+  if (C::walk == WALK_UNIFORM) return lay.total_bytes;
   if (C::walk == WALK_LANE_LDS_ALL) return lay.total_bytes;
   return lds_links * (uint32_t)sizeof(DLink<R>);
 }
@@ -201,14 +203,16 @@ template <class R, class C> RT_DEV SceneView<R, C> make_view(const DeviceScene<R
   uint32_t shade_sub = 0;    // ... whose blob offsets are reduced by this much
   v.top = nullptr;
   v.n_top = 0;
+  const uint8_t* lane = g;   // base for per-lane gathers of shapes / objects
   if constexpr (C::walk == WALK_UNIFORM) {
-    stage_to_lds(lds, g + sc.lay.materials_off, sc.lay.total_bytes - sc.lay.materials_off);
+    stage_to_lds(lds, g, sc.lay.total_bytes);  // small by construction; links/shapes/objects are ALSO read from global by scalar loads
     shade = lds;
-    shade_sub = sc.lay.materials_off;
+    lane = lds;
   } else if constexpr (C::walk == WALK_LANE_LDS_ALL) {
     stage_to_lds(lds, g, sc.lay.total_bytes);
     geom = lds;
     shade = lds;
+    lane = lds;
   } else {
     stage_to_lds(lds, g + sc.lay.links_off, sc.lds_links * (uint32_t)sizeof(DLink<R>));
     v.top = reinterpret_cast<const DLink<R>*>(lds);
@@ -219,6 +223,8 @@ template <class R, class C> RT_DEV SceneView<R, C> make_view(const DeviceScene<R
   v.links = reinterpret_cast<const DLink<R>*>(geom + sc.lay.links_off);
   v.shapes = reinterpret_cast<const DShape<R>*>(geom + sc.lay.shapes_off);
   v.objects = reinterpret_cast<const DObject<R>*>(geom + sc.lay.objects_off);
+  v.shapes_lane = reinterpret_cast<const DShape<R>*>(lane + sc.lay.shapes_off);
+  v.objects_lane = reinterpret_cast<const DObject<R>*>(lane + sc.lay.objects_off);
   v.materials = reinterpret_cast<const DMaterial<R>*>(shade + (sc.lay.materials_off - shade_sub));
   v.textures = reinterpret_cast<const DTexture<R>*>(shade + (sc.lay.textures_off - shade_sub));
   v.perlins = reinterpret_cast<const DPerlin<R>*>(shade + (sc.lay.perlins_off - shade_sub));

@@ -2,7 +2,7 @@
 // (src/texture.rs), Perlin noise (src/perlin.rs), the miss shader (src/color.rs:41-51), primary-ray
 // generation (src/render.rs:230-234 + src/camera.rs:62-72) and the final colour conversion (src/color.rs:14-27).
 #pragma once
-#include "device_trace.h"
+#include "device_trace_deferred.h"
 
 namespace rtd {
 

@@ -336,38 +336,4 @@ RT_DEV bool traverse_lane(const SceneView<R, C>& sv, int start, const Ray<R>& ra
   return any;
 }
 
-// The same walk for a small tree whose entries are stored in visiting order (an entry's hit link is the next index, its
-// miss link a larger one).  `cur` is the same in every lane of the wave, so the entry and whatever it refers to are
-// fetched once per wave by scalar loads; `want` is the entry this lane's own traversal needs next, and a lane only
-// acts on the entries it wants.  Lane by lane this performs exactly the tests of traverse_lane, in the same order.
-template <class R, class C>
-RT_DEV bool traverse_uniform(const SceneView<R, C>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
-  V3<R> inv_d((R)1 / ray.d.x, (R)1 / ray.d.y, (R)1 / ray.d.z);
-  R closest = t_max;
-  bool any = false;
-  const int end = (int)sv.n_links;
-  int want = start;
-  for (int cur = start; cur < end; ++cur) {
-    if (__ballot(want == cur) == 0ull) continue;
-    const DLink<R> lk = sv.link_uniform(cur);
-    const int miss = lk.miss < 0 ? end : lk.miss;
-    if (lk.hit & LEAF_FLAG) {
-      if (want == cur) {
-        if (leaf_hit<R, C, 0>(sv, lk.hit, ray, t_min, closest, rec, media, org)) { closest = rec.t; any = true; }
-        want = miss;
-      }
-    } else {
-      if (want == cur) want = aabb_hit(lk, ray, inv_d, t_min, closest) ? cur + 1 : miss;
-    }
-  }
-  return any;
-}
-
-// world.hit(ray, t_min, t_max, rec).  May be called from divergent code: lanes without a ray simply do not take part.
-template <class R, class C>
-RT_DEV bool closest_hit(const SceneView<R, C>& sv, int root, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
-  if constexpr (C::walk == WALK_UNIFORM) return traverse_uniform<R, C>(sv, root, ray, t_min, t_max, rec, media, org);
-  else return traverse_lane<R, C, 0>(sv, root, ray, t_min, t_max, rec, media, org);
-}
-
 }  // namespace rtd

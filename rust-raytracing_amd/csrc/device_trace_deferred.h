@@ -1,0 +1,283 @@
+// Closest hit for the small-scene presets (WALK_UNIFORM): the walk only keeps the winning candidate (t, object, side)
+// and the HitRecord is built once, after the walk, from those three values.
+//
+// The reference fills a complete HitRecord on every accepted candidate (src/sphere.rs:64-70, src/aarect.rs:99-105,
+// src/hittable.rs:229-239,146-148).  Every field of the final record is a function of the ray, the winning primitive
+// and its t alone, evaluated here with the same expressions in the same order, so the result is the same bit for bit;
+// what is saved is rewriting a dozen registers per accepted candidate in every wave.  The one thing a deferred record
+// cannot reproduce is a stale (u, v) left behind by an earlier candidate when the winner is a shape that does not write
+// them (moving sphere, medium): presets containing those shapes together with (u, v)-reading textures use the eager walk.
+#pragma once
+#include "device_trace.h"
+
+namespace rtd {
+
+constexpr int SIDE_MEDIUM = 6;  // candidate produced by a ConstantMedium (sides -1..5 are surfaces)
+
+// Per-ray reciprocal directions.  f64: 1/d for the slab test and true division for the plane distance, as the reference
+// writes them.  f32: one hardware reciprocal per component (1 ulp) serves both.
+template <class R> struct RayInv;
+template <> struct RayInv<double> {
+  V3<double> inv, d;
+  RT_DEV explicit RayInv(V3<double> dir) : inv(1.0 / dir.x, 1.0 / dir.y, 1.0 / dir.z), d(dir) {}
+  template <int AXIS> RT_DEV double quot(double num) const { return num / (AXIS == 0 ? d.x : AXIS == 1 ? d.y : d.z); }
+};
+template <> struct RayInv<float> {
+  V3<float> inv;
+  RT_DEV explicit RayInv(V3<float> dir) : inv(__builtin_amdgcn_rcpf(dir.x), __builtin_amdgcn_rcpf(dir.y), __builtin_amdgcn_rcpf(dir.z)) {}
+  template <int AXIS> RT_DEV float quot(float num) const { return num * (AXIS == 0 ? inv.x : AXIS == 1 ? inv.y : inv.z); }
+};
+
+// src/aarect.rs:88-97: distance to the plane, range test, in-plane bounds (closed).
+template <class R, int AXIS>
+RT_DEV bool rect_t(R a0, R a1, R b0, R b1, R k, const Ray<R>& ray, const RayInv<R>& ri, R t_min, R t_max, R& t_out) {
+  constexpr int A = (AXIS == 0) ? 1 : 0;
+  constexpr int B = (AXIS == 2) ? 1 : 2;
+  const R o[3] = {ray.o.x, ray.o.y, ray.o.z};
+  const R d[3] = {ray.d.x, ray.d.y, ray.d.z};
+  R t = ri.template quot<AXIS>(k - o[AXIS]);
+  if (t < t_min || t > t_max) return false;
+  R a = o[A] + t * d[A];
+  R b = o[B] + t * d[B];
+  if (a < a0 || a > a1 || b < b0 || b > b1) return false;
+  t_out = t;
+  return true;
+}
+
+// hit() of one shape reduced to its t (and the side of a box).  `self_side` as in shape_hit.
+template <class R, class C>
+RT_DEV bool shape_t(const DShape<R>& s, const Ray<R>& ray, const RayInv<R>& ri, R t_min, R t_max, int self_side, R& t_out, int& side_out) {
+  const bool self = Guard<R>::on && self_side != -2;
+  bool hit = false;
+  switch (s.tag) {
+    case SH_SPHERE: if constexpr (C::has(F_SPHERE)) {
+      R root;
+      if (sphere_roots(V3<R>(s.p[0], s.p[1], s.p[2]), ray, s.p[3], t_min, t_max, root, self)) { t_out = root; side_out = -1; hit = true; }
+    } break;
+    case SH_MOVING: if constexpr (C::has(F_MOVING)) {
+      R root;
+      if (sphere_roots(moving_center(s, ray.time), ray, s.p[6], t_min, t_max, root, self)) { t_out = root; side_out = -1; hit = true; }
+    } break;
+    case SH_RECT_XY: if constexpr (C::has(F_RECT)) { if (!self && rect_t<R, 2>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], ray, ri, t_min, t_max, t_out)) { side_out = -1; hit = true; } } break;
+    case SH_RECT_XZ: if constexpr (C::has(F_RECT)) { if (!self && rect_t<R, 1>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], ray, ri, t_min, t_max, t_out)) { side_out = -1; hit = true; } } break;
+    case SH_RECT_YZ: if constexpr (C::has(F_RECT)) { if (!self && rect_t<R, 0>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], ray, ri, t_min, t_max, t_out)) { side_out = -1; hit = true; } } break;
+    case SH_BOX: if constexpr (C::has(F_BOX)) {  // six sides in the order of src/box_struct.rs:22-71; a later side wins a tie
+      R lox = s.p[0], loy = s.p[1], loz = s.p[2], hix = s.p[3], hiy = s.p[4], hiz = s.p[5];
+      R closest = t_max;
+      if (!(self && self_side == 0) && rect_t<R, 2>(lox, hix, loy, hiy, hiz, ray, ri, t_min, closest, closest)) { side_out = 0; hit = true; }
+      if (!(self && self_side == 1) && rect_t<R, 2>(lox, hix, loy, hiy, loz, ray, ri, t_min, closest, closest)) { side_out = 1; hit = true; }
+      if (!(self && self_side == 2) && rect_t<R, 1>(lox, hix, loz, hiz, hiy, ray, ri, t_min, closest, closest)) { side_out = 2; hit = true; }
+      if (!(self && self_side == 3) && rect_t<R, 1>(lox, hix, loz, hiz, loy, ray, ri, t_min, closest, closest)) { side_out = 3; hit = true; }
+      if (!(self && self_side == 4) && rect_t<R, 0>(loy, hiy, loz, hiz, hix, ray, ri, t_min, closest, closest)) { side_out = 4; hit = true; }
+      if (!(self && self_side == 5) && rect_t<R, 0>(loy, hiy, loz, hiz, lox, ray, ri, t_min, closest, closest)) { side_out = 5; hit = true; }
+      if (hit) t_out = closest;
+    } break;
+    default: break;
+  }
+  return hit;
+}
+
+// Ray in the space of the geometry below [Translate(] [RotateY(] (src/hittable.rs:141,214-223).
+template <class R> RT_DEV void to_local(const DObject<R>& ob, const Ray<R>& ray, Ray<R>& moved, Ray<R>& local) {
+  moved = ray;
+  if (ob.flags & OBJ_TRANSLATE) moved.o = ray.o - V3<R>(ob.offset[0], ob.offset[1], ob.offset[2]);
+  local = moved;
+  if (ob.flags & OBJ_ROTATE_Y) {
+    local.o.x = ob.cos_theta * moved.o.x - ob.sin_theta * moved.o.z;
+    local.o.z = ob.sin_theta * moved.o.x + ob.cos_theta * moved.o.z;
+    local.d.x = ob.cos_theta * moved.d.x - ob.sin_theta * moved.d.z;
+    local.d.z = ob.sin_theta * moved.d.x + ob.cos_theta * moved.d.z;
+    local.time = (R)0;
+  }
+}
+
+template <class R, class C>
+RT_DEV bool boundary_t(const DObject<R>& ob, const DShape<R>& s, const Ray<R>& ray, const RayInv<R>& ri, R t_min, R t_max, int self_side, R& t_out,
+                       int& side_out) {
+  if constexpr (C::has(F_XFORM)) {
+    if (ob.flags & (OBJ_TRANSLATE | OBJ_ROTATE_Y)) {
+      Ray<R> moved, local;
+      to_local(ob, ray, moved, local);
+      if (ob.flags & OBJ_ROTATE_Y) {
+        const RayInv<R> rl(local.d);
+        return shape_t<R, C>(s, local, rl, t_min, t_max, self_side, t_out, side_out);
+      }
+      return shape_t<R, C>(s, local, ri, t_min, t_max, self_side, t_out, side_out);  // a translation keeps the direction
+    }
+  }
+  return shape_t<R, C>(s, ray, ri, t_min, t_max, self_side, t_out, side_out);
+}
+
+// One leaf of the tree (object index uniform across the wave).
+template <class R, class C>
+RT_DEV bool leaf_t(const SceneView<R, C>& sv, uint32_t leaf_word, const Ray<R>& ray, const RayInv<R>& ri, R t_min, R t_max, Stream& media, Origin org,
+                   R& t_out, int& side_out) {
+  const int obj = (int)(leaf_word & LEAF_INDEX_MASK);
+  const DShape<R> s = sv.shape(obj);
+  const int self_side = org.leaf() == obj ? org.side() : -2;
+  if constexpr (C::has(F_XFORM) || C::has(F_MEDIUM)) {
+    if (!(leaf_word & LEAF_SIMPLE)) {
+      const DObject<R> ob = sv.object(obj);
+      if constexpr (C::has(F_MEDIUM)) {
+        if (ob.flags & OBJ_MEDIUM) {  // src/constant_medium.rs:41-111
+          const R inf = Lim<R>::inf();
+          R t1, t2;
+          int unused;
+          if (!boundary_t<R, C>(ob, s, ray, ri, -inf, inf, -2, t1, unused)) return false;
+          R t_after = t1 + (R)0.0001;
+          if constexpr (Guard<R>::on) {
+            if (!(t_after > t1)) t_after = nextafterf(t1, Lim<float>::inf());  // see object_hit
+          }
+          if (!boundary_t<R, C>(ob, s, ray, ri, t_after, inf, -2, t2, unused)) return false;
+          if (t1 < t_min) t1 = t_min;
+          if (t2 > t_max) t2 = t_max;
+          if (t1 >= t2) return false;
+          if (t1 < (R)0) t1 = (R)0;
+          R ray_length = length(ray.d);
+          R distance_inside_boundary = (t2 - t1) * ray_length;
+          R hit_distance = ob.neg_inv_density * gen_log01(media, (R)0);
+          if (hit_distance > distance_inside_boundary) return false;
+          t_out = t1 + hit_distance / ray_length;
+          side_out = SIDE_MEDIUM;
+          return true;
+        }
+      }
+      return boundary_t<R, C>(ob, s, ray, ri, t_min, t_max, self_side, t_out, side_out);
+    }
+  }
+  return shape_t<R, C>(s, ray, ri, t_min, t_max, self_side, t_out, side_out);
+}
+
+// The HitRecord of candidate (t, leaf, side), gathered per lane.
+template <class R, class C> RT_DEV void finalize_hit(const SceneView<R, C>& sv, const Ray<R>& ray, R t, int leaf, int side, Rec<R>& rec) {
+  const DShape<R> s = sv.shapes_lane[leaf];
+  rec.t = t;
+  rec.obj = s.obj_id;
+  rec.sub = s.sub_id;
+  rec.side = side;
+  rec.leaf = leaf;
+  rec.uv_lazy = 0;
+  DObject<R> ob;
+  ob.flags = 0u;
+  if constexpr (C::has(F_XFORM) || C::has(F_MEDIUM)) ob = sv.objects_lane[leaf];
+  if constexpr (C::has(F_MEDIUM)) {
+    if (side == SIDE_MEDIUM) {  // src/constant_medium.rs:97-108
+      rec.p = ray.at(t);
+      rec.n = V3<R>((R)1, (R)0, (R)0);
+      rec.front = 1;
+      rec.mat = ob.medium_material;
+      rec.side = -1;
+      rec.leaf = -1;
+      return;
+    }
+  }
+  rec.mat = s.material;
+  Ray<R> moved = ray, local = ray;
+  if constexpr (C::has(F_XFORM)) to_local(ob, ray, moved, local);
+  if (s.tag == SH_SPHERE || s.tag == SH_MOVING) {
+    if constexpr (C::has(F_SPHERE) || C::has(F_MOVING)) {  // src/sphere.rs:64-70, src/moving_sphere.rs:64-69
+      V3<R> center = s.tag == SH_SPHERE ? V3<R>(s.p[0], s.p[1], s.p[2]) : moving_center(s, local.time);
+      R radius = s.tag == SH_SPHERE ? s.p[3] : s.p[6];
+      V3<R> p = local.at(t);
+      V3<R> outward = vdiv(p - center, radius);
+      rec.p = p;
+      rec.set_face_normal(local.d, outward);
+      if constexpr (C::has(F_UV)) {
+        if (s.tag == SH_SPHERE) { rec.u = outward.x; rec.v = outward.y; rec.uw = outward.z; rec.uv_lazy = 1; }
+      }
+    }
+  } else {
+    // plane of a rectangle or of a box side: constant axis and its coordinate k
+    int axis;
+    R k;
+    if (s.tag == SH_BOX) {
+      axis = side < 2 ? 2 : (side < 4 ? 1 : 0);
+      k = side == 0 ? s.p[5] : side == 1 ? s.p[2] : side == 2 ? s.p[4] : side == 3 ? s.p[1] : side == 4 ? s.p[3] : s.p[0];
+    } else {
+      axis = s.tag == SH_RECT_XY ? 2 : (s.tag == SH_RECT_XZ ? 1 : 0);
+      k = s.p[4];
+    }
+    if constexpr (C::has(F_UV)) {  // src/aarect.rs:93-100
+      R oa = axis == 0 ? local.o.y : local.o.x, da = axis == 0 ? local.d.y : local.d.x;
+      R ob2 = axis == 2 ? local.o.y : local.o.z, db = axis == 2 ? local.d.y : local.d.z;
+      R a = oa + t * da, b = ob2 + t * db;
+      R a0 = s.p[0], a1 = s.p[1], b0 = s.p[2], b1 = s.p[3];
+      if (s.tag == SH_BOX) {  // extents of the side rectangle, src/box_struct.rs:22-71
+        a0 = axis == 0 ? s.p[1] : s.p[0];
+        a1 = axis == 0 ? s.p[4] : s.p[3];
+        b0 = axis == 2 ? s.p[1] : s.p[2];
+        b1 = axis == 2 ? s.p[4] : s.p[5];
+      }
+      rec.u = (a - a0) / (a1 - a0);
+      rec.v = (b - b0) / (b1 - b0);
+    }
+    V3<R> outward(axis == 0 ? (R)1 : (R)0, axis == 1 ? (R)1 : (R)0, axis == 2 ? (R)1 : (R)0);
+    rec.set_face_normal(local.d, outward);
+    V3<R> p = local.at(t);
+    if constexpr (Guard<R>::on) {  // see rect_hit
+      if (axis == 0) p.x = k;
+      if (axis == 1) p.y = k;
+      if (axis == 2) p.z = k;
+    }
+    rec.p = p;
+  }
+  if constexpr (C::has(F_XFORM)) {
+    if (ob.flags & OBJ_ROTATE_Y) {  // src/hittable.rs:229-239
+      V3<R> p = rec.p, n = rec.n;
+      p.x = ob.cos_theta * rec.p.x + ob.sin_theta * rec.p.z;
+      p.z = -ob.sin_theta * rec.p.x + ob.cos_theta * rec.p.z;
+      n.x = ob.cos_theta * rec.n.x + ob.sin_theta * rec.n.z;
+      n.z = -ob.sin_theta * rec.n.x + ob.cos_theta * rec.n.z;
+      rec.p = p;
+      rec.set_face_normal(local.d, n);
+    }
+    if (ob.flags & OBJ_TRANSLATE) {  // src/hittable.rs:146-148
+      rec.p = rec.p + V3<R>(ob.offset[0], ob.offset[1], ob.offset[2]);
+      rec.set_face_normal(moved.d, rec.n);
+    }
+  }
+}
+
+// BVHNode::hit over a small tree stored in visiting order (an entry's hit link is the next index, its miss link a larger
+// one).  `cur` is the same in every lane of the wave, so the entry and whatever it refers to are fetched once per wave
+// by scalar loads; `want` is the entry this lane's own traversal needs next, and a lane only acts on the entries it
+// wants.  Lane by lane this performs exactly the tests of traverse_lane, in the same order, with the same shrinking t_max.
+template <class R, class C>
+RT_DEV bool traverse_uniform(const SceneView<R, C>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
+  const RayInv<R> ri(ray.d);
+  R closest = t_max;
+  int best_leaf = -1, best_side = -1;
+  const int end = (int)sv.n_links;
+  int want = start;
+  for (int cur = start; cur < end; ++cur) {
+    if (__ballot(want == cur) == 0ull) continue;
+    const DLink<R> lk = sv.link_uniform(cur);
+    const int miss = lk.miss < 0 ? end : lk.miss;
+    if (lk.hit & LEAF_FLAG) {
+      if (want == cur) {
+        R t;
+        int side;
+        if (leaf_t<R, C>(sv, lk.hit, ray, ri, t_min, closest, media, org, t, side)) {
+          closest = t;
+          best_leaf = (int)(lk.hit & LEAF_INDEX_MASK);
+          best_side = side;
+        }
+        want = miss;
+      }
+    } else {
+      if (want == cur) want = aabb_hit(lk, ray, ri.inv, t_min, closest) ? cur + 1 : miss;
+    }
+  }
+  if (best_leaf < 0) return false;
+  finalize_hit<R, C>(sv, ray, closest, best_leaf, best_side, rec);
+  return true;
+}
+
+// world.hit(ray, t_min, t_max, rec).  May be called from divergent code: lanes without a ray simply do not take part.
+template <class R, class C>
+RT_DEV bool closest_hit(const SceneView<R, C>& sv, int root, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
+  if constexpr (C::walk == WALK_UNIFORM) return traverse_uniform<R, C>(sv, root, ray, t_min, t_max, rec, media, org);
+  else return traverse_lane<R, C, 0>(sv, root, ray, t_min, t_max, rec, media, org);
+}
+
+}  // namespace rtd

@@ -58,7 +58,11 @@ def test_first_hit_random_rays_f64(gpu, rtamd, oracle, earth_rgb, name):
     assert (oh["hit"] == 1).mean() > 0.05, "ray batch barely hits the scene"
     assert t_err.max() < 1e-11, t_err.max()
     assert p_err.max() < 1e-11 and n_err.max() < 1e-9
-    uv_err = np.abs(np.stack([gh["u"], gh["v"]], 1)[ok] - np.stack([oh["u"], oh["v"]], 1)[ok]).max()
+    # (u, v) of a medium hit are whatever an earlier candidate left in the reference's shared record
+    # (src/constant_medium.rs never writes them; no texture of an Isotropic material reads them): not compared.
+    iso = np.array([int(m["tag"]) == 4 for m in hs.materials()])
+    surf = ok & ~iso[np.clip(oh["material"], 0, None)]
+    uv_err = np.abs(np.stack([gh["u"], gh["v"]], 1)[surf] - np.stack([oh["u"], oh["v"]], 1)[surf]).max()
     assert uv_err < 1e-9, uv_err
 
 
