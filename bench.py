@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--pipeline", choices=["auto", "fused", "sorted"], default="auto")
+    ap.add_argument("--pipeline", choices=["auto", "fused", "sorted", "persistent"], default="auto")
     ap.add_argument("--samples-per-pass", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the bounded CPU sample")
@@ -73,7 +73,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     prec = rtamd.F64 if args.precision == "f64" else rtamd.F32
-    pipe = {"auto": rtamd.PIPELINE_AUTO, "fused": rtamd.PIPELINE_FUSED, "sorted": rtamd.PIPELINE_SORTED}[args.pipeline]
+    pipe = {"auto": rtamd.PIPELINE_AUTO, "fused": rtamd.PIPELINE_FUSED, "sorted": rtamd.PIPELINE_SORTED,
+            "persistent": rtamd.PIPELINE_PERSISTENT}[args.pipeline]
     tdtype = torch.float64 if prec == rtamd.F64 else torch.float32
     earth = os.path.join(REPO, "rust-raytracing_amd", "assets", "earthmap.ppm")
     scene = rtamd.Scene(args.scene, width=args.width, aspect=args.aspect, spp=args.spp, depth=args.depth, earth_path=earth)

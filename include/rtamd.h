@@ -40,11 +40,15 @@ extern "C" {
 #define RT_PRECISION_F32 0
 #define RT_PRECISION_F64 1
 
-/* Bounce pipeline: FUSED = one trace+shade kernel per bounce; SORTED = trace
- * kernel writing hit records binned by material class + shade kernel. */
+/* Pipeline.  FUSED = per-bounce ray queues, one trace+shade kernel per bounce;
+ * SORTED = per-bounce ray queues, trace kernel writing hit records binned by
+ * material class + shade kernel; PERSISTENT = one launch per frame, every lane
+ * follows whole paths and lanes whose path ended take the next unstarted
+ * (pixel, sample) in place.  All three produce the same per-sample radiance. */
 #define RT_PIPELINE_AUTO 0
 #define RT_PIPELINE_FUSED 1
 #define RT_PIPELINE_SORTED 2
+#define RT_PIPELINE_PERSISTENT 3
 
 /* ---- scene description (flattened `SceneConfig`, src/scenes.rs:33-41) ---- */
 

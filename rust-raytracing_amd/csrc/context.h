@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -33,8 +34,9 @@ constexpr uint32_t kLdsAllMax = 64u * 1024u;  // stage the whole scene in LDS up
 constexpr uint32_t kLdsTopMax = 32u * 1024u;  // otherwise stage this many bytes of top-level BVH links
 constexpr uint64_t kTargetPathsPerPass = 64ull << 20;
 constexpr uint32_t kMaxDepth = 4096;
+constexpr uint32_t kRayCountWords = 16 + 8 * 4 * 4096;  // ray counter, then 8 diagnostic words per wave of up to 4096 workgroups
 constexpr uint32_t kSegments = 64;  // queue segments (a multiple of the 8 XCDs; at most the workgroup size)
-constexpr uint32_t kCounterWords = (kMaxDepth + 2) * kSegments * 9;  // per bounce and segment: queue count + 8 class counts
+constexpr uint32_t kCounterWords = (kMaxDepth + 2) * kSegments * 11;  // per bounce and segment: queue count, 2 chunk cursors, 8 class counts
 
 template <class R> struct SceneImage {
   uint8_t* d_blob = nullptr;
@@ -79,6 +81,15 @@ namespace rti {
 template <class R> SceneImage<R>& image_of(rt_context* c);
 template <> inline SceneImage<float>& image_of<float>(rt_context* c) { return c->sf; }
 template <> inline SceneImage<double>& image_of<double>(rt_context* c) { return c->sd; }
+
+// Workgroups per CU that stay resident for a kernel: the runtime's estimate, at most 8 (two waves per SIMD and workgroup), and one
+// less than the estimate when that leaves a margin (the estimate has been seen one too high for kernels near an SGPR allocation
+// step).  The kernels take their work from cursors, so a grid above or below the true residency is only a small inefficiency.
+inline uint32_t resident_blocks(int api_estimate) {
+  if (const char* e = getenv("RTAMD_BLOCKS_PER_CU")) return (uint32_t)std::max(1, atoi(e));
+  if (api_estimate <= 0) return 4u;
+  return (uint32_t)std::min(api_estimate, 8);
+}
 
 inline uint32_t grid_for(const rt_context* c, uint64_t n, uint32_t blocks_per_cu) {
   uint64_t want = (n + kBlock - 1) / kBlock;

@@ -74,7 +74,10 @@ template <class R> RT_DEV V3<R> refract(V3<R> uv, V3<R> n, R etai_over_etat) {  
 RT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t& o0, uint32_t& o1,
                           uint32_t& o2, uint32_t& o3) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+#ifndef RT_X_ROUNDS
+#define RT_X_ROUNDS 10
+#endif
+  for (int r = 0; r < RT_X_ROUNDS; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -150,10 +153,18 @@ template <class R> RT_DEV V3<R> random_range_vec(Stream& s, R lo, R hi) {  // sr
   return V3<R>(a, b, c);
 }
 template <class R> RT_DEV V3<R> random_in_unit_sphere(Stream& s) {  // src/vec3.rs:81-88
+#ifdef RT_X_BOUND
+  for (int guard = 0; guard < 64; ++guard) {
+#else
   for (;;) {
+#endif
     V3<R> p = random_range_vec<R>(s, (R)-1, (R)1);
+#ifdef RT_X_NOREJECT
+    return p;
+#endif
     if (length_squared(p) < (R)1) return p;
   }
+  return V3<R>((R)0.5, (R)0, (R)0);
 }
 template <class R> RT_DEV V3<R> random_unit_vector(Stream& s) { return unit_vector(random_in_unit_sphere<R>(s)); }  // src/vec3.rs:90-92
 template <class R> RT_DEV V3<R> random_in_unit_disk(Stream& s) {  // src/vec3.rs:103-111

@@ -9,13 +9,16 @@ using namespace rtd;
 template <class R> struct KernelTable {
   uint32_t (*lds_bytes)(const BlobLayout& lay, uint32_t lds_links);
   void (*bounce_fused)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, PathQueue<R> in, PathQueue<R> out,
-                       uint32_t* counters, unsigned long long* ray_count, R* accum, uint32_t bounce);
+                       uint32_t* counters, uint32_t* cursors, unsigned long long* ray_count, R* accum, uint32_t bounce);
+  void (*paths_persistent)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, unsigned long long total_paths,
+                           unsigned long long* path_cursor, unsigned long long* ray_count, R* accum);
+  int (*resident_blocks_per_cu)(int kernel, uint32_t lds);  // kernel: 0 bounce_fused, 1 trace, 2 shade, 3 paths_persistent
   void (*trace)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, PathQueue<R> in, HitQueue<R> hits,
-                uint32_t* counters, unsigned long long* ray_count, uint32_t* class_counters, uint32_t* class_index, uint32_t capacity, R* accum,
+                uint32_t* counters, uint32_t* cursors, unsigned long long* ray_count, uint32_t* class_counters, uint32_t* class_index, uint32_t capacity, R* accum,
                 uint32_t bounce);
   void (*shade)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, PathQueue<R> in, HitQueue<R> hits,
-                PathQueue<R> out, uint32_t* counters, const uint32_t* class_counters, const uint32_t* class_index, uint32_t capacity, R* accum,
-                uint32_t bounce);
+                PathQueue<R> out, uint32_t* counters, uint32_t* cursors, const uint32_t* class_counters, const uint32_t* class_index, uint32_t capacity,
+                R* accum, uint32_t bounce);
   void (*first_hit)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const RayIO* rays, uint32_t n, HitIO* hits, uint64_t seed);
   void (*sample_radiance)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, uint32_t W, uint32_t H, uint32_t max_depth,
                           const uint32_t* pixel, const uint32_t* sample, uint32_t n, uint64_t seed, double* out, double* path_out, uint32_t max_vertices);
@@ -27,19 +30,35 @@ template <class R, class C> KernelTable<R> make_table() {
   KernelTable<R> t;
   t.lds_bytes = [](const BlobLayout& lay, uint32_t lds_links) { return lds_bytes_for<R, C>(lay, lds_links); };
   t.bounce_fused = [](uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, PathQueue<R> in, PathQueue<R> out,
-                      uint32_t* counters, unsigned long long* ray_count, R* accum, uint32_t bounce) {
-    hipLaunchKernelGGL((k_bounce_fused<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, in, out, counters, ray_count, accum, bounce);
+                      uint32_t* counters, uint32_t* cursors, unsigned long long* ray_count, R* accum, uint32_t bounce) {
+    hipLaunchKernelGGL((k_bounce_fused<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, in, out, counters, cursors, ray_count, accum, bounce);
+  };
+  t.paths_persistent = [](uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, unsigned long long total_paths,
+                          unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
+    hipLaunchKernelGGL((k_paths_persistent<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
+  };
+  t.resident_blocks_per_cu = [](int kernel, uint32_t lds) {
+    int n = 0;
+    hipError_t e = hipErrorInvalidValue;
+    switch (kernel) {
+      case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_fused<R, C>, (int)kBlockThreads, lds); break;
+      case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<R, C>, (int)kBlockThreads, lds); break;
+      case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade<R, C>, (int)kBlockThreads, lds); break;
+      case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths_persistent<R, C>, (int)kBlockThreads, lds); break;
+      default: break;
+    }
+    return e == hipSuccess ? n : -1;
   };
   t.trace = [](uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, PathQueue<R> in, HitQueue<R> hits,
-               uint32_t* counters, unsigned long long* ray_count, uint32_t* class_counters, uint32_t* class_index, uint32_t capacity, R* accum,
-               uint32_t bounce) {
-    hipLaunchKernelGGL((k_trace<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, in, hits, counters, ray_count, class_counters, class_index,
+               uint32_t* counters, uint32_t* cursors, unsigned long long* ray_count, uint32_t* class_counters, uint32_t* class_index, uint32_t capacity,
+               R* accum, uint32_t bounce) {
+    hipLaunchKernelGGL((k_trace<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, in, hits, counters, cursors, ray_count, class_counters, class_index,
                        capacity, accum, bounce);
   };
   t.shade = [](uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, PathQueue<R> in, HitQueue<R> hits,
-               PathQueue<R> out, uint32_t* counters, const uint32_t* class_counters, const uint32_t* class_index, uint32_t capacity, R* accum,
-               uint32_t bounce) {
-    hipLaunchKernelGGL((k_shade<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, in, hits, out, counters, class_counters, class_index,
+               PathQueue<R> out, uint32_t* counters, uint32_t* cursors, const uint32_t* class_counters, const uint32_t* class_index, uint32_t capacity,
+               R* accum, uint32_t bounce) {
+    hipLaunchKernelGGL((k_shade<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, in, hits, out, counters, cursors, class_counters, class_index,
                        capacity, accum, bounce);
   };
   t.first_hit = [](uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const RayIO* rays, uint32_t n, HitIO* hits, uint64_t seed) {

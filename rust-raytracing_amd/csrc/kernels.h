@@ -77,6 +77,31 @@ template <class R> RT_DEV void add_radiance(R* accum, uint32_t pixel, V3<R> c) {
   }
 }
 
+// Diagnostic build (-DRT_STAMPS): every wave sums the shader-clock cycles between phase boundaries of the bounce loop (all
+// outstanding memory operations are drained at each boundary so a phase owns its own latency) and adds them to a slot of its own
+// (8 words per wave) behind the ray counter.  No stamp executes in the normal build.
+#ifdef RT_STAMPS
+#define RT_STAMP_INIT() unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long stamp_t = __builtin_amdgcn_s_memtime()
+#define RT_STAMP(k)                                                        \
+  do {                                                                     \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");            \
+    unsigned long long now_ = __builtin_amdgcn_s_memtime();                \
+    stamp_acc[k] += now_ - stamp_t;                                        \
+    stamp_t = now_;                                                        \
+  } while (0)
+#define RT_STAMP_FLUSH(base)                                               \
+  do {                                                                     \
+    if ((threadIdx.x & 63u) == 0u) {                                       \
+      unsigned long long* slot_ = (base) + 16 + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * 8u; \
+      for (int k_ = 0; k_ < 8; ++k_) slot_[k_] += stamp_acc[k_];           \
+    }                                                                      \
+  } while (0)
+#else
+#define RT_STAMP_INIT() do {} while (0)
+#define RT_STAMP(k) do {} while (0)
+#define RT_STAMP_FLUSH(base) do {} while (0)
+#endif
+
 struct FrameParams {
   uint32_t width, height, n_pixels;
   uint32_t sample_base;  // first sample index of this pass
@@ -91,16 +116,30 @@ struct FrameParams {
 };
 
 struct Segment {
-  uint32_t seg, first, step, origin;  // segment id, first local index of this workgroup, local stride, first slot of the segment
+  uint32_t seg, origin;  // segment id of this workgroup, first slot of the segment
 };
 RT_DEV Segment segment_of_block(const FrameParams& fp) {
   Segment g;
   g.seg = blockIdx.x % fp.n_seg;
-  g.first = (blockIdx.x / fp.n_seg) * blockDim.x;
-  g.step = (gridDim.x / fp.n_seg) * blockDim.x;
   g.origin = g.seg * fp.seg_cap;
   return g;
 }
+
+// Work distribution inside a segment: every wave takes the next 64 queue entries from the segment's cursor, so the split
+// does not depend on how many workgroups the hardware keeps resident and waves with cheap rays simply take more chunks.
+// The request for the following chunk is issued before the current one is processed and read when it is needed.
+struct ChunkCursor {
+  uint32_t* cursor;
+  uint32_t pending;  // lane 0: first entry of the next chunk
+  RT_DEV explicit ChunkCursor(uint32_t* c) : cursor(c), pending(0) { request(); }
+  RT_DEV void request() {
+    if ((threadIdx.x & 63u) == 0u) pending = atomicAdd(cursor, 64u);
+  }
+  RT_DEV uint32_t take() {  // wave-uniform
+    uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)pending);
+    return base;
+  }
+};
 
 // Primary rays for one pass: path index = sample_in_pass * n_pixels + pixel, so adjacent lanes hold adjacent pixels.
 template <class R>
@@ -126,32 +165,46 @@ __global__ __launch_bounds__(256) void k_gen_primary(DeviceScene<R> sc, FramePar
 // One bounce for every queued ray: closest hit, miss shader or emitted + scatter, compaction into the next queue.
 template <class R, class C>
 __global__ __launch_bounds__(256) void k_bounce_fused(DeviceScene<R> sc, FrameParams fp, PathQueue<R> in, PathQueue<R> out,
-                                                      uint32_t* counters, unsigned long long* ray_count, R* accum, uint32_t bounce) {
+                                                      uint32_t* counters, uint32_t* cursors, unsigned long long* ray_count, R* accum,
+                                                      uint32_t bounce) {
   extern __shared__ __align__(16) uint8_t lds[];
   const Segment sg = segment_of_block(fp);
   const uint32_t n_in = counters[bounce * fp.n_seg + sg.seg];
-  if (sg.first >= n_in) return;
-  if (sg.first == 0 && threadIdx.x == 0) atomicAdd(ray_count, (unsigned long long)n_in);
+  if (n_in == 0u) return;
   const SceneView<R, C> sv = make_view<R, C>(sc, lds);
   const bool last = bounce + 1u >= fp.max_depth;  // ray_color(depth == 0) contributes nothing (src/render.rs:151-153)
   uint32_t* const out_count = counters + (bounce + 1u) * fp.n_seg + sg.seg;
-  for (uint32_t base = sg.first; base < n_in; base += sg.step) {
-    const uint32_t j = base + threadIdx.x;
+  ChunkCursor chunks(cursors + bounce * fp.n_seg + sg.seg);
+  RT_STAMP_INIT();
+  for (;;) {
+    const uint32_t base = chunks.take();
+    RT_STAMP(0);
+    if (base >= n_in) break;
+    const uint32_t j = base + (threadIdx.x & 63u);
     const uint32_t i = sg.origin + j;
     bool alive = false;
     PathState<R> st;
+    if (j < n_in) st = load_path(in, i);
+    chunks.request();  // behind the loads: memory operations complete in issue order, so the loads do not wait for this atomic
+    if (base == 0u && (threadIdx.x & 63u) == 0u) atomicAdd(ray_count, (unsigned long long)n_in);
+    RT_STAMP(1);
+    bool hit = false;
+    Rec<R> rec;
     if (j < n_in) {
-      st = load_path(in, i);
       Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
-      Rec<R> rec;
-      if (!closest_hit<R, C>(sv, sc.root_link, st.ray, (R)0.001, Lim<R>::inf(), rec, media, st.org)) {
-        add_radiance(accum, st.pixel, st.thr * background_color<R, C>(sc.background, st.ray.d));
+      hit = closest_hit<R, C>(sv, sc.root_link, st.ray, (R)0.001, Lim<R>::inf(), rec, media, st.org);
+    }
+    RT_STAMP(2);
+    V3<R> radiance;
+    if (j < n_in) {
+      if (!hit) {
+        radiance = st.thr * background_color<R, C>(sc.background, st.ray.d);
       } else {
         Stream rng(fp.seed, st.pixel, st.sample, bounce, STAGE_SCATTER);
         V3<R> emitted, attenuation;
         Ray<R> scattered;
         alive = shade_hit<R, C>(sv, st.ray, rec, rng, emitted, attenuation, scattered);
-        add_radiance(accum, st.pixel, st.thr * emitted);
+        radiance = st.thr * emitted;
         if (alive) {
           st.thr = st.thr * attenuation;
           st.ray = scattered;
@@ -159,11 +212,97 @@ __global__ __launch_bounds__(256) void k_bounce_fused(DeviceScene<R> sc, FramePa
         }
       }
     }
+    RT_STAMP(3);
+    if (j < n_in) add_radiance(accum, st.pixel, radiance);
+    RT_STAMP(4);
     if (!last) {
       uint32_t slot = sg.origin + compact_slot(alive, out_count);
+      RT_STAMP(5);
       if (alive) store_path(out, slot, st);
+      RT_STAMP(6);
     }
   }
+  RT_STAMP_FLUSH(ray_count);
+}
+
+// ---- persistent pipeline: whole paths per lane, dead lanes refilled in place ----
+// Every lane carries one path through all of its bounces.  At the top of each iteration the lanes whose path has ended take
+// the next unstarted (pixel, sample) pairs - ranks by ballot / prefix count inside the wave, path indices in blocks of
+// kPathGrab per wave from one global cursor - so the wave stays full until the frame runs out of paths.  There are no ray
+// queues: nothing is written to memory between bounces except the radiance sums.  A path's random streams are keyed by
+// (pixel, sample, bounce), so its result does not depend on which lane or iteration it ran in.
+constexpr uint32_t kPathGrab = 2048;
+
+template <class R, class C>
+__global__ __launch_bounds__(256) void k_paths_persistent(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
+                                                          unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const SceneView<R, C> sv = make_view<R, C>(sc, lds);
+  const uint32_t lane = threadIdx.x & 63u;
+  unsigned long long grab_next = 0, grab_end = 0;  // wave-uniform: unstarted path indices this wave owns
+  bool exhausted = false;                          // wave-uniform: the cursor has passed total_paths
+  bool active = false;
+  uint32_t bounce = 0;
+  unsigned long long n_rays = 0;
+  PathState<R> st;
+  for (;;) {
+    unsigned long long dead = __ballot(!active);
+    while (dead != 0ull && !exhausted) {
+      if (grab_next == grab_end) {
+        unsigned long long b = 0;
+        if (lane == 0u) b = atomicAdd(path_cursor, (unsigned long long)kPathGrab);
+        uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+        uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+        b = ((unsigned long long)hi << 32) | lo;
+        if (b >= total_paths) { exhausted = true; break; }
+        grab_next = b;
+        grab_end = b + kPathGrab < total_paths ? b + kPathGrab : total_paths;
+      }
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
+      const uint32_t n_dead = (uint32_t)__popcll(dead);
+      const unsigned long long avail = grab_end - grab_next;
+      const uint32_t n_take = avail < (unsigned long long)n_dead ? (uint32_t)avail : n_dead;
+      if (!active && rank < n_take) {
+        const unsigned long long path = grab_next + rank;
+        const uint32_t s = (uint32_t)(path / fp.n_pixels);
+        st.pixel = (uint32_t)(path - (unsigned long long)s * fp.n_pixels);
+        st.sample = fp.sample_base + s;
+        st.ray = primary_ray<R>(sc.camera, fp.width, fp.height, st.pixel, st.sample, fp.seed);
+        st.thr = V3<R>((R)1, (R)1, (R)1);
+        st.org = Origin();
+        bounce = 0;
+        active = true;
+      }
+      grab_next += n_take;
+      dead = __ballot(!active);
+    }
+    const unsigned long long live = __ballot(active);
+    if (live == 0ull) break;
+    n_rays += (unsigned long long)__popcll(live);
+    if (active) {
+      Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
+      Rec<R> rec;
+      if (!closest_hit<R, C>(sv, sc.root_link, st.ray, (R)0.001, Lim<R>::inf(), rec, media, st.org)) {
+        add_radiance(accum, st.pixel, st.thr * background_color<R, C>(sc.background, st.ray.d));
+        active = false;
+      } else {
+        Stream rng(fp.seed, st.pixel, st.sample, bounce, STAGE_SCATTER);
+        V3<R> emitted, attenuation;
+        Ray<R> scattered;
+        const bool alive = shade_hit<R, C>(sv, st.ray, rec, rng, emitted, attenuation, scattered);
+        add_radiance(accum, st.pixel, st.thr * emitted);
+        ++bounce;
+        if (alive && bounce < fp.max_depth) {  // ray_color(depth == 0) contributes nothing (src/render.rs:151-153)
+          st.thr = st.thr * attenuation;
+          st.ray = scattered;
+          st.org = Origin(rec.leaf, rec.side);
+        } else {
+          active = false;
+        }
+      }
+    }
+  }
+  if (lane == 0u && n_rays != 0ull) atomicAdd(ray_count, n_rays);
 }
 
 // ---- material-sorted pipeline: trace kernel + shade kernel ----
@@ -177,16 +316,20 @@ template <class R> struct HitQueue {
 // class_counters: 8 counters per segment for this bounce (MAT_CLASSES used); class_index[(cls * n_seg + seg) * seg_cap + k] = ray slot.
 template <class R, class C>
 __global__ __launch_bounds__(256) void k_trace(DeviceScene<R> sc, FrameParams fp, PathQueue<R> in, HitQueue<R> hits, uint32_t* counters,
-                                               unsigned long long* ray_count, uint32_t* class_counters, uint32_t* class_index,
+                                               uint32_t* cursors, unsigned long long* ray_count, uint32_t* class_counters, uint32_t* class_index,
                                                uint32_t capacity, R* accum, uint32_t bounce) {
   extern __shared__ __align__(16) uint8_t lds[];
   const Segment sg = segment_of_block(fp);
   const uint32_t n_in = counters[bounce * fp.n_seg + sg.seg];
-  if (sg.first >= n_in) return;
-  if (sg.first == 0 && threadIdx.x == 0) atomicAdd(ray_count, (unsigned long long)n_in);
+  if (n_in == 0u) return;
   const SceneView<R, C> sv = make_view<R, C>(sc, lds);
-  for (uint32_t base = sg.first; base < n_in; base += sg.step) {
-    const uint32_t j = base + threadIdx.x;
+  ChunkCursor chunks(cursors + bounce * fp.n_seg + sg.seg);
+  for (;;) {
+    const uint32_t base = chunks.take();
+    if (base >= n_in) break;
+    chunks.request();
+    if (base == 0u && (threadIdx.x & 63u) == 0u) atomicAdd(ray_count, (unsigned long long)n_in);
+    const uint32_t j = base + (threadIdx.x & 63u);
     const uint32_t i = sg.origin + j;
     int cls = -1;
     if (j < n_in) {
@@ -218,7 +361,7 @@ __global__ __launch_bounds__(256) void k_trace(DeviceScene<R> sc, FrameParams fp
 
 template <class R, class C>
 __global__ __launch_bounds__(256) void k_shade(DeviceScene<R> sc, FrameParams fp, PathQueue<R> in, HitQueue<R> hits, PathQueue<R> out,
-                                               uint32_t* counters, const uint32_t* class_counters, const uint32_t* class_index,
+                                               uint32_t* counters, uint32_t* cursors, const uint32_t* class_counters, const uint32_t* class_index,
                                                uint32_t capacity, R* accum, uint32_t bounce) {
   extern __shared__ __align__(16) uint8_t lds[];
   const Segment sg = segment_of_block(fp);
@@ -229,12 +372,16 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene<R> sc, FrameParams fp
     total += class_counters[sg.seg * 8u + k];
     cls_end[k] = total;
   }
-  if (sg.first >= total) return;
+  if (total == 0u) return;
   const SceneView<R, C> sv = make_view<R, C>(sc, lds);
   const bool last = bounce + 1u >= fp.max_depth;
   uint32_t* const out_count = counters + (bounce + 1u) * fp.n_seg + sg.seg;
-  for (uint32_t base = sg.first; base < total; base += sg.step) {
-    uint32_t w = base + threadIdx.x;
+  ChunkCursor chunks(cursors + bounce * fp.n_seg + sg.seg);
+  for (;;) {
+    const uint32_t base = chunks.take();
+    if (base >= total) break;
+    chunks.request();
+    uint32_t w = base + (threadIdx.x & 63u);
     bool alive = false;
     PathState<R> st;
     if (w < total) {

@@ -149,15 +149,55 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
     accum = reinterpret_cast<R*>(c->accum);
     HIP_TRY(hipMemsetAsync(accum, 0, n_pixels * 4 * sizeof(R), c->stream));
   }
+  if (p.pipeline == RT_PIPELINE_PERSISTENT || p.pipeline == RT_PIPELINE_AUTO) {
+    // one launch for the whole sample range; no ray queues
+    FrameParams fp{};
+    fp.width = p.width; fp.height = p.height; fp.n_pixels = (uint32_t)n_pixels;
+    fp.sample_base = p.sample_begin; fp.n_paths = 0; fp.max_depth = p.max_depth; fp.seed = p.seed;
+    fp.n_seg = kSegments; fp.seg_cap = 0;
+    const unsigned long long total_paths = (unsigned long long)n_pixels * n_samples;
+    HIP_TRY(hipMemsetAsync(c->d_ray_count, 0, sizeof(unsigned long long) * 16, c->stream));  // word 0 rays, word 8 path cursor
+    const uint32_t bpc = resident_blocks(im.table.resident_blocks_per_cu(3, im.lds_bytes));
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->n_cus * bpc, (total_paths + kBlock - 1) / kBlock));
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    if (p.max_depth > 0 && total_paths > 0)
+      im.table.paths_persistent(grid, im.lds_bytes, c->stream, im.dev, fp, total_paths, c->d_ray_count + 8, c->d_ray_count, accum);
+    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    HIP_TRY(hipGetLastError());
+    unsigned long long rays = 0;
+    HIP_TRY(hipMemcpyAsync(&rays, c->d_ray_count, sizeof(rays), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
+    if (stats) {
+      stats->rays = rays;
+      stats->camera_rays = n_pixels * n_samples;
+      stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+      stats->bounce_kernel_ms = ms;
+      stats->bounce_kernel_launches = 1;
+      stats->gen_kernel_ms = 0.0;
+      stats->passes = 1;
+      stats->lds_bytes = im.lds_bytes;
+      stats->scene_in_lds = (uint32_t)im.preset;
+    }
+    return RT_OK;
+  }
   uint32_t spp_pass = p.samples_per_pass ? p.samples_per_pass : (uint32_t)std::max<uint64_t>(1, kTargetPathsPerPass / n_pixels);
   spp_pass = std::max(1u, std::min(spp_pass, std::max(1u, n_samples)));
   if (n_pixels * spp_pass > 0x7FFFFFFFull) return fail(RT_E_INVALID, "width*height*samples_per_pass exceeds 2^31-1");
-  const uint32_t seg_cap = (uint32_t)(((n_pixels * spp_pass + kSegments - 1) / kSegments + 63) / 64 * 64);
+  // Segment capacity: a whole number of 64-entry chunks, and an ODD number of them, so that the byte distance between the segments
+  // (and, with the pad below, between the arrays) is an odd multiple of 1 KiB: the 64 segment streams that advance in step then
+  // spread over all memory channels instead of landing on the few that a power-of-two distance selects.
+  uint32_t seg_chunks = (uint32_t)(((n_pixels * spp_pass + kSegments - 1) / kSegments + 63) / 64);
+  seg_chunks |= 1u;
+  const uint32_t seg_cap = seg_chunks * 64u;
   const uint64_t cap = (uint64_t)seg_cap * kSegments;
   const bool sorted = p.pipeline == RT_PIPELINE_SORTED;
   // workspace: two ray queues (3 arrays each) [+ hit queue (3 arrays) + class index lists]
-  size_t q_bytes = (size_t)cap * sizeof(R4);
-  size_t ws_bytes = q_bytes * 6 + (((size_t)cap * 4 + 255) & ~(size_t)255) * 2 + (sorted ? q_bytes * 3 + (size_t)cap * 4 * MAT_CLASSES : 0);
+  const size_t kArrayPad = 5u * 1024u;
+  size_t q_bytes = (size_t)cap * sizeof(R4) + kArrayPad;
+  size_t org_bytes = (((size_t)cap * 4 + 255) & ~(size_t)255) + kArrayPad;
+  size_t ws_bytes = q_bytes * 6 + org_bytes * 2 + (sorted ? q_bytes * 3 + (size_t)cap * 4 * MAT_CLASSES : 0);
   int rc = ensure_ws(c, ws_bytes);
   if (rc) return rc;
   uint8_t* w = reinterpret_cast<uint8_t*>(c->ws);
@@ -168,7 +208,7 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
     q[k].c = reinterpret_cast<R4*>(w); w += q_bytes;
   }
   for (int k = 0; k < 2; ++k) {
-    q[k].org = reinterpret_cast<uint32_t*>(w); w += ((size_t)cap * 4 + 255) & ~(size_t)255;
+    q[k].org = reinterpret_cast<uint32_t*>(w); w += org_bytes;
   }
   HitQueue<R> hq{};
   uint32_t* class_index = nullptr;
@@ -178,34 +218,45 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
     hq.c = reinterpret_cast<R4*>(w); w += q_bytes;
     class_index = reinterpret_cast<uint32_t*>(w);
   }
+  // counter block: queue counts, cursors of the first and of the second kernel of a bounce (each (max_depth + 2) * kSegments words,
+  // zeroed together), then the class counters at a fixed offset
+  const size_t per_array = (size_t)kSegments * (p.max_depth + 2);
   uint32_t* counters = c->d_counters;
-  uint32_t* class_counters = c->d_counters + (size_t)(kMaxDepth + 2) * kSegments;
-  HIP_TRY(hipMemsetAsync(c->d_ray_count, 0, sizeof(unsigned long long), c->stream));
+  uint32_t* cursors_a = counters + per_array;
+  uint32_t* cursors_b = cursors_a + per_array;
+  uint32_t* class_counters = c->d_counters + (size_t)(kMaxDepth + 2) * kSegments * 3;
+  #ifdef RT_STAMPS
+  HIP_TRY(hipMemsetAsync(c->d_ray_count, 0, sizeof(unsigned long long) * kRayCountWords, c->stream));  // ray counter + diagnostic words
+#else
+  HIP_TRY(hipMemsetAsync(c->d_ray_count, 0, sizeof(unsigned long long) * 16, c->stream));
+#endif
 
   double bounce_ms = 0.0, gen_ms = 0.0;
   uint64_t launches = 0, passes = 0;
-  const size_t counter_bytes = sizeof(uint32_t) * (size_t)kSegments * ((size_t)(kMaxDepth + 2) + (sorted ? (size_t)(p.max_depth + 1) * 8 : 0));
+  const size_t class_bytes = sizeof(uint32_t) * (size_t)kSegments * (size_t)(p.max_depth + 1) * 8;
   for (uint32_t s0 = p.sample_begin; s0 < p.sample_end; s0 += spp_pass) {
     uint32_t ns = std::min(spp_pass, p.sample_end - s0);
     FrameParams fp{};
     fp.width = p.width; fp.height = p.height; fp.n_pixels = (uint32_t)n_pixels;
     fp.sample_base = s0; fp.n_paths = (uint32_t)(n_pixels * ns); fp.max_depth = p.max_depth; fp.seed = p.seed;
     fp.n_seg = kSegments; fp.seg_cap = seg_cap;
-    HIP_TRY(hipMemsetAsync(counters, 0, sorted ? counter_bytes : sizeof(uint32_t) * (size_t)kSegments * (p.max_depth + 2), c->stream));
+    HIP_TRY(hipMemsetAsync(counters, 0, sizeof(uint32_t) * per_array * 3, c->stream));
+    if (sorted) HIP_TRY(hipMemsetAsync(class_counters, 0, class_bytes, c->stream));
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     launch_gen_primary<R>(grid_for(c, fp.n_paths, 8), c->stream, im.dev, fp, q[0], counters);
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-    const uint32_t grid = grid_for(c, fp.n_paths, 8);
+    const uint32_t grid = grid_for(c, fp.n_paths, resident_blocks(im.table.resident_blocks_per_cu(sorted ? 1 : 0, im.lds_bytes)));
+    const uint32_t grid_shade = sorted ? grid_for(c, fp.n_paths, resident_blocks(im.table.resident_blocks_per_cu(2, im.lds_bytes))) : grid;
     for (uint32_t b = 0; b < p.max_depth; ++b) {
       PathQueue<R>& in = q[b & 1u];
       PathQueue<R>& out = q[(b + 1u) & 1u];
       if (!sorted) {
-        im.table.bounce_fused(grid, im.lds_bytes, c->stream, im.dev, fp, in, out, counters, c->d_ray_count, accum, b);
+        im.table.bounce_fused(grid, im.lds_bytes, c->stream, im.dev, fp, in, out, counters, cursors_a, c->d_ray_count, accum, b);
         launches += 1;
       } else {
         uint32_t* cc = class_counters + (size_t)b * 8 * kSegments;
-        im.table.trace(grid, im.lds_bytes, c->stream, im.dev, fp, in, hq, counters, c->d_ray_count, cc, class_index, (uint32_t)cap, accum, b);
-        im.table.shade(grid, im.lds_bytes, c->stream, im.dev, fp, in, hq, out, counters, cc, class_index, (uint32_t)cap, accum, b);
+        im.table.trace(grid, im.lds_bytes, c->stream, im.dev, fp, in, hq, counters, cursors_a, c->d_ray_count, cc, class_index, (uint32_t)cap, accum, b);
+        im.table.shade(grid_shade, im.lds_bytes, c->stream, im.dev, fp, in, hq, out, counters, cursors_b, cc, class_index, (uint32_t)cap, accum, b);
         launches += 2;
       }
     }
@@ -222,6 +273,20 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
   unsigned long long rays = 0;
   HIP_TRY(hipMemcpyAsync(&rays, c->d_ray_count, sizeof(rays), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+#ifdef RT_STAMPS
+  {
+    std::vector<unsigned long long> all(kRayCountWords);
+    HIP_TRY(hipMemcpy(all.data(), c->d_ray_count, sizeof(unsigned long long) * kRayCountWords, hipMemcpyDeviceToHost));
+    unsigned long long st[9] = {0};
+    for (size_t w = 16; w + 8 <= kRayCountWords; w += 8)
+      for (int k = 0; k < 8; ++k) st[1 + k] += all[w + k];
+    double tot = 0;
+    for (int k = 1; k < 9; ++k) tot += (double)st[k];
+    fprintf(stderr, "[stamps] wave cycles by phase (take, load, trace, shade, accumulate, slot, store):");
+    for (int k = 1; k < 8; ++k) fprintf(stderr, " %.1f%%", 100.0 * (double)st[k] / tot);
+    fprintf(stderr, "  total %.3e cycles, %.0f per wave pass of 64 rays\n", tot, tot / ((double)rays / 64.0));
+  }
+#endif
   if (stats) {
     stats->rays = rays;
     stats->camera_rays = n_pixels * n_samples;

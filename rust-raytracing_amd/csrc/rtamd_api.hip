@@ -144,7 +144,7 @@ int check_render_params(const rt_context* c, const rt_render_params* p) {
   if (p->sample_end < p->sample_begin) return fail(RT_E_INVALID, "sample_end < sample_begin");
   if (p->max_depth > kMaxDepth) return fail(RT_E_INVALID, "max_depth exceeds 4096");
   if (p->precision != RT_PRECISION_F32 && p->precision != RT_PRECISION_F64) return fail(RT_E_INVALID, "unknown precision");
-  if (p->pipeline < RT_PIPELINE_AUTO || p->pipeline > RT_PIPELINE_SORTED) return fail(RT_E_INVALID, "unknown pipeline");
+  if (p->pipeline < RT_PIPELINE_AUTO || p->pipeline > RT_PIPELINE_PERSISTENT) return fail(RT_E_INVALID, "unknown pipeline");
   return RT_OK;
 }
 
@@ -173,7 +173,7 @@ int rt_create(rt_context** out, int device) {
   for (auto& ev : c->ev)
     if (hipEventCreate(&ev) != hipSuccess) return cleanup(RT_E_HIP, "hipEventCreate failed");
   if (hipMalloc((void**)&c->d_counters, sizeof(uint32_t) * kCounterWords) != hipSuccess) return cleanup(RT_E_HIP, "hipMalloc counters failed");
-  if (hipMalloc((void**)&c->d_ray_count, sizeof(unsigned long long)) != hipSuccess) return cleanup(RT_E_HIP, "hipMalloc ray counter failed");
+  if (hipMalloc((void**)&c->d_ray_count, sizeof(unsigned long long) * rti::kRayCountWords) != hipSuccess) return cleanup(RT_E_HIP, "hipMalloc ray counter failed");
   *out = c;
   return RT_OK;
 }

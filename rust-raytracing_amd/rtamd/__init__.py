@@ -13,12 +13,12 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-BUILD_DIR = os.path.join(os.path.dirname(_HERE), "_build")
+BUILD_DIR = os.environ.get("RTAMD_BUILD_DIR") or os.path.join(os.path.dirname(_HERE), "_build")  # override: A/B builds
 LIB_PATH = os.path.join(BUILD_DIR, "librtamd.so")
 HOST_LIB_PATH = os.path.join(BUILD_DIR, "librtamd_host.so")
 
 F32, F64 = 0, 1
-PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_SORTED = 0, 1, 2
+PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_SORTED, PIPELINE_PERSISTENT = 0, 1, 2, 3
 
 SCENES = {
     "random": 0, "two-spheres": 1, "two-perlin-spheres": 2, "earth": 3, "simple-light": 4,

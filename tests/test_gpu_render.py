@@ -38,13 +38,13 @@ def test_per_sample_radiance_f64(gpu, rtamd, oracle, earth_rgb, name):
 
 
 @pytest.mark.parametrize("name", ALL_SCENES)
-@pytest.mark.parametrize("pipeline", ["fused", "sorted"])
+@pytest.mark.parametrize("pipeline", ["fused", "sorted", "persistent"])
 def test_frame_sums_f64(gpu, rtamd, oracle, earth_rgb, name, pipeline):
     w, spp = SMALL[name]
     hs, os_ = make_pair(rtamd, oracle, name, earth=earth_rgb, width=w, spp=spp)
     gpu.upload(hs)
     want, cnt, _ = os_.render(0, spp, seed=77)
-    pl = rtamd.PIPELINE_FUSED if pipeline == "fused" else rtamd.PIPELINE_SORTED
+    pl = {"fused": rtamd.PIPELINE_FUSED, "sorted": rtamd.PIPELINE_SORTED, "persistent": rtamd.PIPELINE_PERSISTENT}[pipeline]
     rgb, got, st = gpu.render(0, spp, precision=rtamd.F64, pipeline=pl, seed=77)
     assert st["rays"] == cnt["rays"], "ray counts differ: gpu %d oracle %d" % (st["rays"], cnt["rays"])
     assert st["camera_rays"] == cnt["camera_rays"]

@@ -12,13 +12,14 @@ spp = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 prec = rtamd.F64 if (len(sys.argv) > 3 and sys.argv[3] == "f64") else rtamd.F32
 spass = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 width = int(sys.argv[5]) if len(sys.argv) > 5 else 1920
+pipe = int(os.environ.get("PROBE_PIPELINE", "0"))
 ctx = rtamd.Context(0)
 sc = rtamd.Scene(scene, width=width, aspect=16.0 / 9.0, spp=spp, earth_path=os.path.join(REPO, "rust-raytracing_amd/assets/earthmap.ppm"))
 ctx.upload(sc)
-for rep in range(3):
+for rep in range(int(os.environ.get("PROBE_REPS", "3"))):
     t0 = time.time()
-    st = ctx.render_accum(None, 0, spp, precision=prec, samples_per_pass=spass)
+    st = ctx.render_accum(None, 0, spp, precision=prec, samples_per_pass=spass, pipeline=pipe)
     dt = time.time() - t0
-print("%s %s spp=%d pass=%d: wall %.1f ms, lib %.1f ms, bounce kernels %.1f ms (%d launches), gen %.1f ms, passes %d, rays %.3fG -> %.2f Grays/s (kernel-only %.2f)"
+print("pipe %d " % pipe + "%s %s spp=%d pass=%d: wall %.1f ms, lib %.1f ms, bounce kernels %.1f ms (%d launches), gen %.1f ms, passes %d, rays %.3fG -> %.2f Grays/s (kernel-only %.2f)"
       % (scene, "f64" if prec else "f32", spp, spass, dt * 1e3, st["seconds"] * 1e3, st["bounce_kernel_ms"], st["bounce_kernel_launches"], st["gen_kernel_ms"],
          st["passes"], st["rays"] / 1e9, st["rays"] / st["seconds"] / 1e9, st["rays"] / (st["bounce_kernel_ms"] * 1e-3) / 1e9))
