@@ -161,7 +161,8 @@ def main():
                              "row-block schedule; the Rust binary cannot be built here" % (args.cpu_spp, args.spp, cnt["rays"]),
                    "seconds": secs, "host_cpus": os.cpu_count()}
         out["cpu_baseline"] = cpu
-        # Roofline of the dominant kernel (the bounce kernel): algorithmic flops per ray x rays / summed kernel time.
+        # Roofline of the dominant kernel (the one launch of k_paths_persistent, or the per-bounce kernels of the queue pipelines):
+        # algorithmic flops per ray x rays / kernel time measured by the library with HIP events on its own stream.
         fpr = flops_per_ray(cnt) if cnt else None
         if fpr is None:
             try:
@@ -169,20 +170,27 @@ def main():
                     fpr = json.load(f).get(args.scene)
             except OSError:
                 fpr = None
+        persistent = args.pipeline in ("auto", "persistent")
         traffic = None
         try:
             with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f).get("%s_%s" % (args.scene, args.precision))
-        except OSError:
+                t = json.load(f).get("%s_%s_%s" % (args.scene, args.precision, "persistent" if persistent else args.pipeline))
+            if t is not None:  # bytes per frame at the profiled sample count -> per launch of this run
+                traffic = t["bytes_per_frame"] * (args.spp / t["spp"]) * (s1 - s0) / args.spp / (launches / max(1, args.steps))
+        except (OSError, KeyError):
             pass
         if fpr is not None and bounce_ms > 0:
             achieved = fpr * rays / (bounce_ms * 1e-3) / 1e12
             peak = VALU_PEAK_F64_TFLOPS if args.precision == "f64" else VALU_PEAK_TFLOPS
-            qb = QUEUE_BYTES_PER_RAY[args.precision]
+            # bytes the algorithm has to move per ray: the queue pipelines read and write one queue entry per ray; the persistent
+            # pipeline keeps paths in registers and only adds finished radiance terms to the pixel sums (16 bytes per path)
+            qb = 16.0 / (rays_all / max(1, args.steps) / (W * H * args.spp)) if persistent else QUEUE_BYTES_PER_RAY[args.precision]
             out["roofline"] = {
                 "bound": "valu", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                "flops_per_ray": fpr, "kernel": "k_bounce_fused", "avg_launch_ms": bounce_ms / max(1.0, launches), "launches": launches,
-                "note": "scene is LDS-resident; no dense contraction, so the vector ALU bounds this path, not MFMA",
+                "flops_per_ray": fpr, "kernel": "k_paths_persistent" if persistent else ("k_bounce_fused" if args.pipeline == "fused" else "k_trace+k_shade"),
+                "avg_launch_ms": bounce_ms / max(1.0, launches), "launches": launches,
+                "note": "no dense contraction on this path (MFMA unused by design) and the scene is cache resident, so the vector ALU bounds it; "
+                        "peak is the FP32 (FP64) vector FMA peak; hbm = the same launches against the HBM roofline",
                 "hbm": {"bound": "hbm", "achieved": qb * rays / (bounce_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": qb * rays / (bounce_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_ray": qb},
             }

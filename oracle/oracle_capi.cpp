@@ -338,8 +338,8 @@ V3<R> sample_radiance(const Scene<R>& sc, uint32_t W, uint32_t H, uint32_t i, ui
   uint32_t y = H - 1 - j;
   uint32_t pixel = y * W + i;
   Stream cam(seed, pixel, s, 0, STAGE_CAMERA);
-  R u_rand = gen01<R>(cam);
-  R v_rand = gen01<R>(cam);
+  R u_rand = gen01_at<R>(cam, 0);
+  R v_rand = gen01_at<R>(cam, 1);
   R u = ((R)i + u_rand) / (R)(W - 1);
   R v = ((R)j + v_rand) / (R)(H - 1);
   Ray<R> ray = sc.camera.get_ray(u, v, cam);

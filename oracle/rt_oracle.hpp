@@ -84,33 +84,50 @@ inline void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
 enum Stage : uint32_t { STAGE_CAMERA = 0, STAGE_MEDIA = 1, STAGE_SCATTER = 2 };
 
 // One random stream = Philox keyed by (pixel, sample); counter =
-// (block index, bounce | stage<<16, seed_lo, seed_hi).  Draw i is 64-bit word
-// (i & 1) of block i/2, word = out[2k+1]<<32 | out[2k].
+// (block, bounce | stage<<16 | half<<20, seed_lo, seed_hi).  Draws are ADDRESSED:
+// draw slot s is the 64-bit word  H[s&3] << 32 | L[s&3]  where H is block s>>2
+// with half = 0 and L the same block with half = 1.  (A single-precision
+// evaluation only ever needs H.)  Slot assignment per stage:
+//   CAMERA   slot 0 = pixel jitter u, 1 = jitter v, 2 = shutter time;
+//            lens-disk candidate c uses slots 4(1+c), 4(1+c)+1
+//   SCATTER  unit-sphere candidate c uses slots 4c, 4c+1, 4c+2 (Lambertian,
+//            Metal fuzz, Isotropic); Dielectric's one uniform is slot 0
+//   MEDIA    sequential: the k-th free-path draw along the ray is slot k
+// The rejection loops of vec3.rs:81-88,103-111 therefore read "the first
+// candidate c = 0, 1, 2, ... inside the unit ball / disk", which is what the
+// sequential loop computes.
 struct Stream {
   uint32_t key[2];
-  uint32_t ctr_hi[3];
-  uint32_t idx = 0;
-  uint32_t blk[4];
+  uint32_t c1, c2, c3;
+  uint32_t seq = 0;             // next sequential slot (MEDIA)
+  uint32_t cached = 0xFFFFFFFFu;  // block held in hi/lo
+  uint32_t hi[4], lo[4];
   Stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, Stage st) {
     key[0] = pixel; key[1] = sample;
-    ctr_hi[0] = bounce | ((uint32_t)st << 16);
-    ctr_hi[1] = (uint32_t)seed; ctr_hi[2] = (uint32_t)(seed >> 32);
+    c1 = bounce | ((uint32_t)st << 16);
+    c2 = (uint32_t)seed; c3 = (uint32_t)(seed >> 32);
   }
-  uint64_t next_u64() {
-    uint32_t k = idx & 1u;
-    if (k == 0) {
-      uint32_t ctr[4] = {idx >> 1, ctr_hi[0], ctr_hi[1], ctr_hi[2]};
-      philox4x32_10(ctr, key, blk);
+  uint64_t word(uint32_t slot) {
+    uint32_t b = slot >> 2, j = slot & 3u;
+    if (b != cached) {
+      uint32_t ch[4] = {b, c1, c2, c3};
+      uint32_t cl[4] = {b, c1 | (1u << 20), c2, c3};
+      philox4x32_10(ch, key, hi);
+      philox4x32_10(cl, key, lo);
+      cached = b;
     }
-    ++idx; ++g_cnt.rng_words;
-    return ((uint64_t)blk[2 * k + 1] << 32) | blk[2 * k];
+    ++g_cnt.rng_words;
+    return ((uint64_t)hi[j] << 32) | lo[j];
   }
+  uint64_t next_u64() { return word(seq++); }
 };
 
 // Uniform conversions.  rand 0.8.5 semantics (third-party, not under
 // /root/reference; restated from its published algorithm, unpinned):
 //   Standard f64      = (u64 >> 11) * 2^-53                       in [0,1)
-//   gen_range(lo..hi) = ((u64 >> 12) * 2^-52) * (hi-lo) + lo      half-open, retry if == hi
+//   gen_range(lo..hi) = ((u64 >> 12) * 2^-52) * (hi-lo) + lo      half-open
+// rand redraws when rounding lands on hi (probability about 2^-52); with
+// addressed draws that case takes the largest value below hi instead.
 // For R=float the top 24 / 23 bits of the same 64-bit word are used so that a
 // float run consumes the stream exactly like the double run.
 template <class R> struct Uni;
@@ -122,15 +139,13 @@ template <> struct Uni<float> {
   static float u01(uint64_t w) { return (float)(w >> 40) * (1.0f / 16777216.0f); }
   static float m01(uint64_t w) { return (float)(w >> 41) * (1.0f / 8388608.0f); }
 };
-template <class R> inline R gen01(Stream& s) { return Uni<R>::u01(s.next_u64()); }
-template <class R> inline R gen_range(Stream& s, R lo, R hi) {
-  R scale = hi - lo;
-  for (;;) {
-    R res = Uni<R>::m01(s.next_u64()) * scale + lo;
-    if (res < hi) return res;
-    scale = std::nextafter(scale, (R)0);
-  }
+template <class R> inline R range_of(uint64_t w, R lo, R hi) {
+  R res = Uni<R>::m01(w) * (hi - lo) + lo;
+  return res < hi ? res : std::nextafter(hi, lo);
 }
+template <class R> inline R gen01_at(Stream& s, uint32_t slot) { return Uni<R>::u01(s.word(slot)); }
+template <class R> inline R gen_range_at(Stream& s, uint32_t slot, R lo, R hi) { return range_of<R>(s.word(slot), lo, hi); }
+template <class R> inline R gen01(Stream& s) { return Uni<R>::u01(s.next_u64()); }  // sequential (MEDIA)
 
 // ---------------------------------------------------------------------------
 // vec3.rs
@@ -164,23 +179,20 @@ template <class R> inline V3<R> operator/(const V3<R>& v, R f) { return ((R)1 / 
 template <class R> inline V3<R> operator-(const V3<R>& v) { return {-v.e[0], -v.e[1], -v.e[2]}; }
 template <class R> inline V3<R> unit_vector(const V3<R>& v) { return v / v.length(); }                         // vec3.rs:77-79
 
-template <class R> inline V3<R> random_range_vec(Stream& s, R lo, R hi) {  // vec3.rs:24-31
-  R a = gen_range<R>(s, lo, hi);
-  R b = gen_range<R>(s, lo, hi);
-  R c = gen_range<R>(s, lo, hi);
-  return {a, b, c};
-}
-template <class R> inline V3<R> random_in_unit_sphere(Stream& s) {  // vec3.rs:81-88
-  for (;;) {
-    V3<R> p = random_range_vec<R>(s, (R)-1, (R)1);
+template <class R> inline V3<R> random_in_unit_sphere(Stream& s) {  // vec3.rs:81-88 over vec3.rs:24-31; candidate c = block c
+  for (uint32_t c = 0;; ++c) {
+    R a = gen_range_at<R>(s, 4 * c + 0, (R)-1, (R)1);
+    R b = gen_range_at<R>(s, 4 * c + 1, (R)-1, (R)1);
+    R d = gen_range_at<R>(s, 4 * c + 2, (R)-1, (R)1);
+    V3<R> p(a, b, d);
     if (p.length_squared() < (R)1) return p;
   }
 }
 template <class R> inline V3<R> random_unit_vector(Stream& s) { return unit_vector(random_in_unit_sphere<R>(s)); }  // vec3.rs:90-92
-template <class R> inline V3<R> random_in_unit_disk(Stream& s) {  // vec3.rs:103-111
-  for (;;) {
-    R a = gen_range<R>(s, (R)-1, (R)1);
-    R b = gen_range<R>(s, (R)-1, (R)1);
+template <class R> inline V3<R> random_in_unit_disk(Stream& s) {  // vec3.rs:103-111; candidate c = block 1 + c of the camera stream
+  for (uint32_t c = 0;; ++c) {
+    R a = gen_range_at<R>(s, 4 * (1 + c) + 0, (R)-1, (R)1);
+    R b = gen_range_at<R>(s, 4 * (1 + c) + 1, (R)-1, (R)1);
     V3<R> p(a, b, 0);
     if (p.length_squared() < (R)1) return p;
   }
@@ -403,7 +415,7 @@ template <class R> struct Dielectric : Material<R> {
     bool cannot_refract = refraction_ratio * sin_theta > (R)1;
     V3<R> direction;
     // `||` short-circuits: the random number is drawn only when refraction is possible.
-    if (cannot_refract || reflectance(cos_theta, refraction_ratio) > gen01<R>(rng))
+    if (cannot_refract || reflectance(cos_theta, refraction_ratio) > gen01_at<R>(rng, 0))
       direction = reflect(unit_direction, rec.normal);
     else
       direction = refract(unit_direction, rec.normal, refraction_ratio);
@@ -880,7 +892,7 @@ template <class R> struct Camera {
     V3<R> rd = lens_radius * random_in_unit_disk<R>(rng);
     V3<R> offset = u * rd.x() + v * rd.y();
     V3<R> direction = lower_left_corner + s * horizontal + t * vertical - origin - offset;
-    R time = gen_range<R>(rng, shutter_open, shutter_close);
+    R time = gen_range_at<R>(rng, 2, shutter_open, shutter_close);
     return Ray<R>{origin + offset, direction, time};
   }
 };

@@ -94,84 +94,116 @@ RT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
 
 enum : uint32_t { STAGE_CAMERA = 0, STAGE_MEDIA = 1, STAGE_SCATTER = 2 };
 
-// One stream per (pixel, sample, bounce, stage): key = (pixel, sample), counter = (block, bounce | stage << 16,
-// seed_lo, seed_hi).  Draw i is the 64-bit word (i & 1) of block i / 2 (word k = out[2k+1] << 32 | out[2k]).
+// One stream per (pixel, sample, bounce, stage): key = (pixel, sample), counter = (block, bounce | stage << 16 | half << 20,
+// seed_lo, seed_hi).  Draws are addressed, not consumed in sequence: draw slot s is the 64-bit word H[s & 3] << 32 | L[s & 3],
+// H = block s >> 2 with half = 0, L = the same block with half = 1.  Slots by stage:
+//   CAMERA   0 = pixel jitter u, 1 = jitter v, 2 = shutter time; lens-disk candidate c = slots 4(1+c), 4(1+c)+1
+//   SCATTER  unit-sphere candidate c = slots 4c, 4c+1, 4c+2; the dielectric's uniform = slot 0
+//   MEDIA    the k-th free-path draw along the ray = slot k
+// A rejection loop reads "the first candidate c = 0, 1, 2, ... that is accepted" (src/vec3.rs:81-88,103-111).
+// The float build uses the top 24 / 23 bits of a word, so it needs H only and it sees the same numbers, rounded, as the double build.
 struct Stream {
-  uint32_t k0, k1, c1, c2, c3, idx, w_lo, w_hi;
+  uint32_t k0, k1, c1, c2, c3, seq;
   RT_DEV Stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t stage)
-      : k0(pixel), k1(sample), c1(bounce | (stage << 16)), c2((uint32_t)seed), c3((uint32_t)(seed >> 32)), idx(0), w_lo(0), w_hi(0) {}
-  RT_DEV uint64_t next_u64() {
-    uint64_t w;
-    if ((idx & 1u) == 0) {
-      uint32_t o0, o1, o2, o3;
-      philox4x32_10(idx >> 1, c1, c2, c3, k0, k1, o0, o1, o2, o3);
-      w_lo = o2; w_hi = o3;
-      w = ((uint64_t)o1 << 32) | o0;
-    } else {
-      w = ((uint64_t)w_hi << 32) | w_lo;
-    }
-    ++idx;
-    return w;
-  }
+      : k0(pixel), k1(sample), c1(bounce | (stage << 16)), c2((uint32_t)seed), c3((uint32_t)(seed >> 32)), seq(0) {}
+  RT_DEV void hi(uint32_t block, uint32_t h[4]) const { philox4x32_10(block, c1, c2, c3, k0, k1, h[0], h[1], h[2], h[3]); }
+  RT_DEV void lo(uint32_t block, uint32_t l[4]) const { philox4x32_10(block, c1 | (1u << 20), c2, c3, k0, k1, l[0], l[1], l[2], l[3]); }
 };
 
-// rand 0.8.5 value conversions: Standard f64 keeps 53 bits; gen_range builds a 52-bit mantissa in [1,2) - 1.
-// The float build takes the top 24 / 23 bits of the same word, so both builds consume the stream alike.
-template <class R> struct Uni;
-template <> struct Uni<double> {
-  RT_DEV static double u01(uint64_t w) { return (double)(w >> 11) * 0x1.0p-53; }
-  RT_DEV static double m01(uint64_t w) { return (double)(w >> 12) * 0x1.0p-52; }
-};
-template <> struct Uni<float> {
-  RT_DEV static float u01(uint64_t w) { return (float)(uint32_t)(w >> 40) * 0x1.0p-24f; }
-  RT_DEV static float m01(uint64_t w) { return (float)(uint32_t)(w >> 41) * 0x1.0p-23f; }
-};
-RT_DEV float next_toward_zero(float x) { return __uint_as_float(__float_as_uint(x) - 1u); }
-RT_DEV double next_toward_zero(double x) { return __longlong_as_double(__double_as_longlong(x) - 1ll); }
+// rand 0.8.5 value conversions: Standard f64 keeps 53 bits; gen_range builds a 52-bit mantissa in [1,2) - 1 and scales it
+// (a result that rounds up to `hi`, probability about 2^-52, takes the largest value below hi).
+RT_DEV float next_toward(float x, float lo) { return x == lo ? x : __uint_as_float(__float_as_uint(x) + ((x > lo) == (x > 0.0f) ? -1 : 1)); }
+RT_DEV double next_toward(double x, double lo) {
+  return x == lo ? x : __longlong_as_double(__double_as_longlong(x) + ((x > lo) == (x > 0.0) ? -1ll : 1ll));
+}
+RT_DEV float u01_of(uint32_t h, uint32_t, float) { return (float)(h >> 8) * 0x1.0p-24f; }
+RT_DEV double u01_of(uint32_t h, uint32_t l, double) { return (double)((((uint64_t)h << 32) | l) >> 11) * 0x1.0p-53; }
+RT_DEV float m01_of(uint32_t h, uint32_t, float) { return (float)(h >> 9) * 0x1.0p-23f; }
+RT_DEV double m01_of(uint32_t h, uint32_t l, double) { return (double)((((uint64_t)h << 32) | l) >> 12) * 0x1.0p-52; }
+template <class R> RT_DEV R range_of(uint32_t h, uint32_t l, R lo, R hi) {  // half-open [lo, hi)
+  R res = m01_of(h, l, (R)0) * (hi - lo) + lo;
+  return res < hi ? res : next_toward(hi, lo);
+}
+// [-1, 1): never rounds up to 1, no guard needed
+template <class R> RT_DEV R signed_unit_of(uint32_t h, uint32_t l) { return m01_of(h, l, (R)0) * (R)2 + (R)-1; }
 
-template <class R> RT_DEV R gen01(Stream& s) { return Uni<R>::u01(s.next_u64()); }
-// ln(U) for the next 53-bit uniform U (free-path sampling, src/constant_medium.rs:91).  A float cannot represent U close
-// to 1, where ln(U) ~ -(1 - U) is tiny, so the float build forms 1 - U exactly from the integer and uses log1p there.
-RT_DEV double gen_log01(Stream& s, double) { return rt_log(Uni<double>::u01(s.next_u64())); }
+// One block of four draws.  The double build fetches the low halves as well.
+template <class R> struct Block;
+template <> struct Block<float> {
+  uint32_t h[4];
+  RT_DEV Block(const Stream& s, uint32_t b) { s.hi(b, h); }
+  RT_DEV float u01(int j) const { return u01_of(h[j], 0u, 0.0f); }
+  RT_DEV float range(int j, float lo, float hi) const { return range_of<float>(h[j], 0u, lo, hi); }
+};
+template <> struct Block<double> {
+  uint32_t h[4], l[4];
+  RT_DEV Block(const Stream& s, uint32_t b) { s.hi(b, h); s.lo(b, l); }
+  RT_DEV double u01(int j) const { return u01_of(h[j], l[j], 0.0); }
+  RT_DEV double range(int j, double lo, double hi) const { return range_of<double>(h[j], l[j], lo, hi); }
+};
+
+// Uniform in [0,1) at the next sequential slot (MEDIA stage) and its logarithm (free-path sampling, src/constant_medium.rs:91).
+// A float cannot represent U close to 1, where ln(U) ~ -(1 - U) is tiny, so the float build forms 1 - U exactly from the
+// 53-bit integer and uses log1p there.
+RT_DEV uint64_t next_word(Stream& s) {
+  uint32_t h[4], l[4];
+  s.hi(s.seq >> 2, h);
+  s.lo(s.seq >> 2, l);
+  uint32_t j = s.seq & 3u;
+  ++s.seq;
+  uint32_t hj = j == 0 ? h[0] : j == 1 ? h[1] : j == 2 ? h[2] : h[3];
+  uint32_t lj = j == 0 ? l[0] : j == 1 ? l[1] : j == 2 ? l[2] : l[3];
+  return ((uint64_t)hj << 32) | lj;
+}
+RT_DEV double gen_log01(Stream& s, double) { return rt_log((double)(next_word(s) >> 11) * 0x1.0p-53); }
 RT_DEV float gen_log01(Stream& s, float) {
-  uint64_t k = s.next_u64() >> 11;
+  uint64_t k = next_word(s) >> 11;
   if (k >= (1ull << 52)) return log1pf(-((float)((1ull << 53) - k) * 0x1.0p-53f));
   return rt_log((float)k * 0x1.0p-53f);
 }
-template <class R> RT_DEV R gen_range(Stream& s, R lo, R hi) {  // half-open [lo, hi)
-  R scale = hi - lo;
-  for (;;) {
-    R res = Uni<R>::m01(s.next_u64()) * scale + lo;
-    if (res < hi) return res;
-    scale = next_toward_zero(scale);
-  }
-}
-template <class R> RT_DEV V3<R> random_range_vec(Stream& s, R lo, R hi) {  // src/vec3.rs:24-31
-  R a = gen_range<R>(s, lo, hi);
-  R b = gen_range<R>(s, lo, hi);
-  R c = gen_range<R>(s, lo, hi);
-  return V3<R>(a, b, c);
-}
-template <class R> RT_DEV V3<R> random_in_unit_sphere(Stream& s) {  // src/vec3.rs:81-88
+
+// src/vec3.rs:81-88: first candidate (three draws in [-1,1)) inside the unit ball; candidate c is block c of the stream.
+RT_DEV V3<float> random_in_unit_sphere(const Stream& s, float) {
 #ifdef RT_X_BOUND
-  for (int guard = 0; guard < 64; ++guard) {
+  for (uint32_t c = 0; c < 64u; ++c) {
 #else
-  for (;;) {
+  for (uint32_t c = 0;; ++c) {
 #endif
-    V3<R> p = random_range_vec<R>(s, (R)-1, (R)1);
+    uint32_t h[4];
+    s.hi(c, h);
+    V3<float> p(signed_unit_of<float>(h[0], 0u), signed_unit_of<float>(h[1], 0u), signed_unit_of<float>(h[2], 0u));
 #ifdef RT_X_NOREJECT
     return p;
 #endif
-    if (length_squared(p) < (R)1) return p;
+    if (length_squared(p) < 1.0f) return p;
   }
-  return V3<R>((R)0.5, (R)0, (R)0);
+  return V3<float>(0.5f, 0.0f, 0.0f);
 }
-template <class R> RT_DEV V3<R> random_unit_vector(Stream& s) { return unit_vector(random_in_unit_sphere<R>(s)); }  // src/vec3.rs:90-92
-template <class R> RT_DEV V3<R> random_in_unit_disk(Stream& s) {  // src/vec3.rs:103-111
+// Double build: the high halves alone decide all but a sliver of candidates (the low halves move a coordinate by less than
+// 2^-31, the squared length by less than 2.8e-9), so the low block is fetched once, for the candidate that passes that test.
+RT_DEV V3<double> random_in_unit_sphere(const Stream& s, double) {
+  uint32_t c = 0;
   for (;;) {
-    R a = gen_range<R>(s, (R)-1, (R)1);
-    R b = gen_range<R>(s, (R)-1, (R)1);
-    V3<R> p(a, b, (R)0);
+    uint32_t h[4];
+    for (;; ++c) {
+      s.hi(c, h);
+      V3<double> q(signed_unit_of<double>(h[0], 0u), signed_unit_of<double>(h[1], 0u), signed_unit_of<double>(h[2], 0u));
+      if (length_squared(q) < 1.0 + 4e-9) break;
+    }
+    uint32_t l[4];
+    s.lo(c, l);
+    V3<double> p(signed_unit_of<double>(h[0], l[0]), signed_unit_of<double>(h[1], l[1]), signed_unit_of<double>(h[2], l[2]));
+    if (length_squared(p) < 1.0) return p;
+    ++c;
+  }
+}
+template <class R> RT_DEV V3<R> random_in_unit_sphere(const Stream& s) { return random_in_unit_sphere(s, (R)0); }
+template <class R> RT_DEV V3<R> random_unit_vector(const Stream& s) { return unit_vector(random_in_unit_sphere<R>(s)); }  // src/vec3.rs:90-92
+// src/vec3.rs:103-111 on the camera stream: candidate c is block 1 + c.
+template <class R> RT_DEV V3<R> random_in_unit_disk(const Stream& s) {
+  for (uint32_t c = 0;; ++c) {
+    Block<R> b(s, 1u + c);
+    V3<R> p(b.range(0, (R)-1, (R)1), b.range(1, (R)-1, (R)1), (R)0);
     if (length_squared(p) < (R)1) return p;
   }
 }

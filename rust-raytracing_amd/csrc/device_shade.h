@@ -121,7 +121,7 @@ RT_DEV bool shade_hit(const SceneView<R, C>& sv, const Ray<R>& ray_in, Rec<R>& r
       R sin_theta = rt_sqrt((R)1 - cos_theta * cos_theta);
       bool cannot_refract = refraction_ratio * sin_theta > (R)1;
       bool do_reflect = cannot_refract;
-      if (!do_reflect) do_reflect = schlick_reflectance(cos_theta, refraction_ratio) > gen01<R>(rng);  // `||` short-circuit
+      if (!do_reflect) do_reflect = schlick_reflectance(cos_theta, refraction_ratio) > Block<R>(rng, 0u).u01(0);  // `||` short-circuit
       scattered.d = do_reflect ? reflect(unit_direction, rec.n) : refract(unit_direction, rec.n, refraction_ratio);
       return true;
     } break;
@@ -151,16 +151,19 @@ template <class R, class C> RT_DEV V3<R> background_color(const DBackground<R>& 
 template <class R>
 RT_DEV Ray<R> primary_ray(const DCamera<R>& cam, uint32_t W, uint32_t H, uint32_t pixel, uint32_t sample, uint64_t seed) {
   uint32_t y = pixel / W, i = pixel - y * W, j = H - 1u - y;
-  Stream rng(seed, pixel, sample, 0u, STAGE_CAMERA);
-  R u_rand = gen01<R>(rng);
-  R v_rand = gen01<R>(rng);
+  const Stream rng(seed, pixel, sample, 0u, STAGE_CAMERA);
+  const Block<R> jitter(rng, 0u);
+  R u_rand = jitter.u01(0);
+  R v_rand = jitter.u01(1);
   R s = ((R)i + u_rand) / (R)(W - 1u);
   R t = ((R)j + v_rand) / (R)(H - 1u);
-  V3<R> rd = cam.lens_radius * random_in_unit_disk<R>(rng);
+  // a pinhole camera (lens_radius == 0) multiplies the disk sample by zero; draws are addressed, so skipping it moves nothing else
+  V3<R> rd((R)0, (R)0, (R)0);
+  if (cam.lens_radius != (R)0) rd = cam.lens_radius * random_in_unit_disk<R>(rng);
   V3<R> offset = rd.x * cam.u + rd.y * cam.v;
   Ray<R> ray;
   ray.d = cam.lower_left_corner + s * cam.horizontal + t * cam.vertical - cam.origin - offset;
-  ray.time = gen_range<R>(rng, cam.t_open, cam.t_close);
+  ray.time = jitter.range(2, cam.t_open, cam.t_close);
   ray.o = cam.origin + offset;
   return ray;
 }

@@ -245,7 +245,9 @@ __global__ __launch_bounds__(256) void k_paths_persistent(DeviceScene<R> sc, Fra
   uint32_t bounce = 0;
   unsigned long long n_rays = 0;
   PathState<R> st;
+  RT_STAMP_INIT();
   for (;;) {
+    RT_STAMP(6);
     unsigned long long dead = __ballot(!active);
     while (dead != 0ull && !exhausted) {
       if (grab_next == grab_end) {
@@ -276,13 +278,19 @@ __global__ __launch_bounds__(256) void k_paths_persistent(DeviceScene<R> sc, Fra
       grab_next += n_take;
       dead = __ballot(!active);
     }
+    RT_STAMP(0);
     const unsigned long long live = __ballot(active);
     if (live == 0ull) break;
     n_rays += (unsigned long long)__popcll(live);
+    bool hit = false;
+    Rec<R> rec;
     if (active) {
       Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
-      Rec<R> rec;
-      if (!closest_hit<R, C>(sv, sc.root_link, st.ray, (R)0.001, Lim<R>::inf(), rec, media, st.org)) {
+      hit = closest_hit<R, C>(sv, sc.root_link, st.ray, (R)0.001, Lim<R>::inf(), rec, media, st.org);
+    }
+    RT_STAMP(1);
+    if (active) {
+      if (!hit) {
         add_radiance(accum, st.pixel, st.thr * background_color<R, C>(sc.background, st.ray.d));
         active = false;
       } else {
@@ -301,7 +309,9 @@ __global__ __launch_bounds__(256) void k_paths_persistent(DeviceScene<R> sc, Fra
         }
       }
     }
+    RT_STAMP(2);
   }
+  RT_STAMP_FLUSH(ray_count);
   if (lane == 0u && n_rays != 0ull) atomicAdd(ray_count, n_rays);
 }
 

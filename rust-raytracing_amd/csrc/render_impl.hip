@@ -156,7 +156,11 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
     fp.sample_base = p.sample_begin; fp.n_paths = 0; fp.max_depth = p.max_depth; fp.seed = p.seed;
     fp.n_seg = kSegments; fp.seg_cap = 0;
     const unsigned long long total_paths = (unsigned long long)n_pixels * n_samples;
+#ifdef RT_STAMPS
+    HIP_TRY(hipMemsetAsync(c->d_ray_count, 0, sizeof(unsigned long long) * kRayCountWords, c->stream));
+#else
     HIP_TRY(hipMemsetAsync(c->d_ray_count, 0, sizeof(unsigned long long) * 16, c->stream));  // word 0 rays, word 8 path cursor
+#endif
     const uint32_t bpc = resident_blocks(im.table.resident_blocks_per_cu(3, im.lds_bytes));
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->n_cus * bpc, (total_paths + kBlock - 1) / kBlock));
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
@@ -167,6 +171,19 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
     unsigned long long rays = 0;
     HIP_TRY(hipMemcpyAsync(&rays, c->d_ray_count, sizeof(rays), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+#ifdef RT_STAMPS
+    {
+      std::vector<unsigned long long> all(kRayCountWords);
+      HIP_TRY(hipMemcpy(all.data(), c->d_ray_count, sizeof(unsigned long long) * kRayCountWords, hipMemcpyDeviceToHost));
+      double st[8] = {0}, tot = 0;
+      for (size_t w = 16; w + 8 <= kRayCountWords; w += 8)
+        for (int k = 0; k < 8; ++k) st[k] += (double)all[w + k];
+      for (int k = 0; k < 8; ++k) tot += st[k];
+      fprintf(stderr, "[stamps] persistent, wave cycles by phase (refill, trace, shade+accumulate, ., ., ., loop top):");
+      for (int k = 0; k < 7; ++k) fprintf(stderr, " %.1f%%", 100.0 * st[k] / tot);
+      fprintf(stderr, "  %.0f cycles per wave iteration of %.1f rays\n", tot / ((double)rays / 64.0) , 64.0);
+    }
+#endif
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
     if (stats) {

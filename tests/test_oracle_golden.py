@@ -124,13 +124,15 @@ def test_philox_published_vectors(oracle):
 
 
 def test_stream_layout(oracle):
-    # draw i = 64-bit word (i & 1) of block i/2; key (pixel, sample); counter (block, bounce | stage << 16, seed_lo, seed_hi)
+    # draw slot s = H[s & 3] << 32 | L[s & 3]; H = Philox block s >> 2 with counter (block, bounce | stage << 16, seed_lo, seed_hi),
+    # L = the same with bit 20 of the second counter word set; key (pixel, sample)
     seed, pixel, sample, bounce, stage = 0x1122334455667788, 12345, 67, 9, 2
-    words = oracle.stream_words(seed, pixel, sample, bounce, stage, 6)
+    words = oracle.stream_words(seed, pixel, sample, bounce, stage, 12)
     for blk in range(3):
-        o = oracle.philox([blk, bounce | (stage << 16), seed & 0xffffffff, seed >> 32], [pixel, sample])
-        assert int(words[2 * blk]) == (int(o[1]) << 32) | int(o[0])
-        assert int(words[2 * blk + 1]) == (int(o[3]) << 32) | int(o[2])
+        h = oracle.philox([blk, bounce | (stage << 16), seed & 0xffffffff, seed >> 32], [pixel, sample])
+        l = oracle.philox([blk, bounce | (stage << 16) | (1 << 20), seed & 0xffffffff, seed >> 32], [pixel, sample])
+        for j in range(4):
+            assert int(words[4 * blk + j]) == (int(h[j]) << 32) | int(l[j])
 
 
 def test_pcg32_reference_stream(oracle):

@@ -1,0 +1,75 @@
+"""Turn gpurun_out/profile_<tag>/ (written by tools/profile_round.sh) into the files kept under profiles/:
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of `python3 bench.py`
+  profiles/<tag>_bench_line.json    the JSON line that run printed
+  profiles/<tag>_pmc.json           per-launch counters of the render kernels (summed over the dispatches of one frame)
+  profiles/pmc_traffic.json         HBM bytes per frame by scene_precision_pipeline key, read by bench.py for roofline.traffic
+FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled (gfx950 tallies a 128-byte request as 64 bytes)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RENDER_KERNELS = ("k_paths_persistent", "k_bounce_fused", "k_trace", "k_shade", "k_gen_primary")
+
+
+def main():
+    tag = sys.argv[1]
+    key = sys.argv[2] if len(sys.argv) > 2 else "cornell-box_f32_persistent"
+    spp = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+    src = os.path.join(REPO, "gpurun_out", "profile_" + tag)
+    dst = os.path.join(REPO, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    for f in glob.glob(os.path.join(src, "trace", "*kernel_stats.csv")):
+        shutil.copy(f, os.path.join(dst, tag + "_kernel_stats.csv"))
+    if os.path.exists(os.path.join(src, "bench_line.json")):
+        shutil.copy(os.path.join(src, "bench_line.json"), os.path.join(dst, tag + "_bench_line.json"))
+    tot = {}
+    launches = {}
+    for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+        if not os.path.isdir(d):
+            continue
+        for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
+            seen = set()
+            with open(f, newline="") as fh:
+                for r in csv.DictReader(fh):
+                    name = r["Kernel_Name"]
+                    kern = next((k for k in RENDER_KERNELS if k in name), None)
+                    if kern is None:
+                        continue
+                    t = tot.setdefault(kern, {})
+                    t[r["Counter_Name"]] = t.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                    if (r["Dispatch_Id"], kern) not in seen and os.path.basename(d) == "pmc_fetch":
+                        seen.add((r["Dispatch_Id"], kern))
+                        launches[kern] = launches.get(kern, 0) + 1
+                        t["duration_ns"] = t.get("duration_ns", 0.0) + float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                        t["vgpr"] = int(r["VGPR_Count"]); t["sgpr"] = int(r["SGPR_Count"]); t["lds"] = int(r["LDS_Block_Size"])
+    out = {"tag": tag, "key": key, "launches": launches, "kernels": tot}
+    fetch = sum(t.get("FETCH_SIZE", 0.0) for t in tot.values()) * 1024.0 * 2.0
+    write = sum(t.get("WRITE_SIZE", 0.0) for t in tot.values()) * 1024.0
+    out["hbm_bytes_per_frame"] = {"fetch_corrected": fetch, "write": write, "total": fetch + write}
+    for kern, t in tot.items():
+        if t.get("SQ_ACTIVE_INST_VALU") and t.get("GRBM_GUI_ACTIVE"):
+            # SQ_ACTIVE_INST_* count quad-cycles summed over waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs
+            simd_cycles = t["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+            t["valu_busy_frac"] = 4.0 * t["SQ_ACTIVE_INST_VALU"] / simd_cycles
+            t["clock_ghz"] = t["GRBM_GUI_ACTIVE"] / 8.0 / t["duration_ns"]
+        if t.get("SQ_THREAD_CYCLES_VALU") and t.get("SQ_ACTIVE_INST_VALU"):
+            t["lanes_active_per_valu_cycle"] = t["SQ_THREAD_CYCLES_VALU"] / t["SQ_ACTIVE_INST_VALU"]
+    with open(os.path.join(dst, tag + "_pmc.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    tp = os.path.join(dst, "pmc_traffic.json")
+    traffic = {}
+    if os.path.exists(tp):
+        with open(tp) as f:
+            traffic = json.load(f)
+    traffic[key] = {"bytes_per_frame": fetch + write, "spp": spp, "fetch_corrected": fetch, "write": write, "from": tag}
+    with open(tp, "w") as f:
+        json.dump(traffic, f, indent=1, sort_keys=True)
+    print(json.dumps(out["hbm_bytes_per_frame"]), {k: {m: v for m, v in t.items() if m in ("valu_busy_frac", "clock_ghz", "lanes_active_per_valu_cycle", "duration_ns")} for k, t in tot.items()})
+
+
+if __name__ == "__main__":
+    main()
