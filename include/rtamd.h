@@ -168,7 +168,7 @@ typedef struct rt_render_params {
   uint32_t max_depth;                /* src/scenes.rs:59 */
   int32_t precision;                 /* RT_PRECISION_* */
   int32_t pipeline;                  /* RT_PIPELINE_* */
-  uint32_t samples_per_pass;         /* samples of every pixel traced together; 0 = choose */
+  uint32_t samples_per_pass;         /* queue pipelines: samples of every pixel traced together; 0 = choose */
   uint64_t seed;                     /* Philox counter words 2,3 */
 } rt_render_params;
 
@@ -176,12 +176,12 @@ typedef struct rt_stats {
   uint64_t rays;        /* closest-hit queries = ray_color calls with depth > 0 (src/render.rs:158) */
   uint64_t camera_rays; /* width*height*(sample_end-sample_begin) */
   double seconds;       /* host wall clock of the call, device idle on return */
-  double bounce_kernel_ms;     /* HIP-event time summed over the bounce kernels (trace+shade) */
+  double bounce_kernel_ms;     /* HIP-event time of the path kernel (PERSISTENT) or summed over the bounce kernels */
   uint64_t bounce_kernel_launches;
   double gen_kernel_ms;        /* HIP-event time of the primary-ray kernels */
   uint64_t passes;
   uint32_t lds_bytes;          /* LDS used per workgroup by the bounce kernel */
-  uint32_t scene_in_lds;       /* 1 = whole scene staged in LDS, 0 = top BVH links only */
+  uint32_t scene_in_lds;       /* kernel preset the scene selected: 0 boxes, 1 smoke, 2 spheres, 3 all (scene in LDS), 4 all (top links in LDS) */
 } rt_stats;
 
 typedef struct rt_context rt_context;
