@@ -515,7 +515,7 @@ void orc_sphere_uv(const double p[3], double* u, double* v) { get_sphere_uv<doub
 void orc_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32_10(ctr, key, out); }
 void orc_stream_words(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t stage, int n, uint64_t* out) {
   Stream s(seed, pixel, sample, bounce, (Stage)stage);
-  for (int i = 0; i < n; ++i) out[i] = s.next_u64();
+  for (int i = 0; i < n; ++i) out[i] = s.word((uint32_t)i);
 }
 void orc_pcg32_words(uint64_t seed, int n, uint32_t* out) {
   Pcg32 g = Pcg32::seed_from_u64(seed);

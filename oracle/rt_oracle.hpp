@@ -92,14 +92,14 @@ enum Stage : uint32_t { STAGE_CAMERA = 0, STAGE_MEDIA = 1, STAGE_SCATTER = 2 };
 //            lens-disk candidate c uses slots 4(1+c), 4(1+c)+1
 //   SCATTER  unit-sphere candidate c uses slots 4c, 4c+1, 4c+2 (Lambertian,
 //            Metal fuzz, Isotropic); Dielectric's one uniform is slot 0
-//   MEDIA    sequential: the k-th free-path draw along the ray is slot k
+//   MEDIA    the free-path draw of ConstantMedium object k is slot k (one
+//            draw per object and ray, whatever order the tree visits them in)
 // The rejection loops of vec3.rs:81-88,103-111 therefore read "the first
 // candidate c = 0, 1, 2, ... inside the unit ball / disk", which is what the
 // sequential loop computes.
 struct Stream {
   uint32_t key[2];
   uint32_t c1, c2, c3;
-  uint32_t seq = 0;             // next sequential slot (MEDIA)
   uint32_t cached = 0xFFFFFFFFu;  // block held in hi/lo
   uint32_t hi[4], lo[4];
   Stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, Stage st) {
@@ -119,7 +119,6 @@ struct Stream {
     ++g_cnt.rng_words;
     return ((uint64_t)hi[j] << 32) | lo[j];
   }
-  uint64_t next_u64() { return word(seq++); }
 };
 
 // Uniform conversions.  rand 0.8.5 semantics (third-party, not under
@@ -145,7 +144,6 @@ template <class R> inline R range_of(uint64_t w, R lo, R hi) {
 }
 template <class R> inline R gen01_at(Stream& s, uint32_t slot) { return Uni<R>::u01(s.word(slot)); }
 template <class R> inline R gen_range_at(Stream& s, uint32_t slot, R lo, R hi) { return range_of<R>(s.word(slot), lo, hi); }
-template <class R> inline R gen01(Stream& s) { return Uni<R>::u01(s.next_u64()); }  // sequential (MEDIA)
 
 // ---------------------------------------------------------------------------
 // vec3.rs
@@ -731,7 +729,7 @@ template <class R> struct ConstantMedium : Hittable<R> {
     if (rec1.t < (R)0) rec1.t = 0;
     R ray_length = ray.direction.length();
     R distance_inside_boundary = (rec2.t - rec1.t) * ray_length;
-    R hit_distance = negative_inverse_density * std::log(gen01<R>(*ctx.media));
+    R hit_distance = negative_inverse_density * std::log(gen01_at<R>(*ctx.media, (uint32_t)obj));  // draw slot = this object's index
     if (hit_distance > distance_inside_boundary) return false;
     rec.t = rec1.t + hit_distance / ray_length;
     rec.p = ray.at(rec.t);

@@ -99,13 +99,13 @@ enum : uint32_t { STAGE_CAMERA = 0, STAGE_MEDIA = 1, STAGE_SCATTER = 2 };
 // H = block s >> 2 with half = 0, L = the same block with half = 1.  Slots by stage:
 //   CAMERA   0 = pixel jitter u, 1 = jitter v, 2 = shutter time; lens-disk candidate c = slots 4(1+c), 4(1+c)+1
 //   SCATTER  unit-sphere candidate c = slots 4c, 4c+1, 4c+2; the dielectric's uniform = slot 0
-//   MEDIA    the k-th free-path draw along the ray = slot k
+//   MEDIA    the free-path draw of ConstantMedium object k = slot k (independent of the order the tree visits objects in)
 // A rejection loop reads "the first candidate c = 0, 1, 2, ... that is accepted" (src/vec3.rs:81-88,103-111).
 // The float build uses the top 24 / 23 bits of a word, so it needs H only and it sees the same numbers, rounded, as the double build.
 struct Stream {
-  uint32_t k0, k1, c1, c2, c3, seq;
+  uint32_t k0, k1, c1, c2, c3;
   RT_DEV Stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t stage)
-      : k0(pixel), k1(sample), c1(bounce | (stage << 16)), c2((uint32_t)seed), c3((uint32_t)(seed >> 32)), seq(0) {}
+      : k0(pixel), k1(sample), c1(bounce | (stage << 16)), c2((uint32_t)seed), c3((uint32_t)(seed >> 32)) {}
   RT_DEV void hi(uint32_t block, uint32_t h[4]) const { philox4x32_10(block, c1, c2, c3, k0, k1, h[0], h[1], h[2], h[3]); }
   RT_DEV void lo(uint32_t block, uint32_t l[4]) const { philox4x32_10(block, c1 | (1u << 20), c2, c3, k0, k1, l[0], l[1], l[2], l[3]); }
 };
@@ -142,22 +142,20 @@ template <> struct Block<double> {
   RT_DEV double range(int j, double lo, double hi) const { return range_of<double>(h[j], l[j], lo, hi); }
 };
 
-// Uniform in [0,1) at the next sequential slot (MEDIA stage) and its logarithm (free-path sampling, src/constant_medium.rs:91).
-// A float cannot represent U close to 1, where ln(U) ~ -(1 - U) is tiny, so the float build forms 1 - U exactly from the
-// 53-bit integer and uses log1p there.
-RT_DEV uint64_t next_word(Stream& s) {
+// ln(U) for the uniform U in [0,1) at a draw slot (free-path sampling, src/constant_medium.rs:91).  A float cannot represent U
+// close to 1, where ln(U) ~ -(1 - U) is tiny, so the float build forms 1 - U exactly from the 53-bit integer and uses log1p there.
+RT_DEV uint64_t word_at(const Stream& s, uint32_t slot) {
   uint32_t h[4], l[4];
-  s.hi(s.seq >> 2, h);
-  s.lo(s.seq >> 2, l);
-  uint32_t j = s.seq & 3u;
-  ++s.seq;
+  s.hi(slot >> 2, h);
+  s.lo(slot >> 2, l);
+  uint32_t j = slot & 3u;
   uint32_t hj = j == 0 ? h[0] : j == 1 ? h[1] : j == 2 ? h[2] : h[3];
   uint32_t lj = j == 0 ? l[0] : j == 1 ? l[1] : j == 2 ? l[2] : l[3];
   return ((uint64_t)hj << 32) | lj;
 }
-RT_DEV double gen_log01(Stream& s, double) { return rt_log((double)(next_word(s) >> 11) * 0x1.0p-53); }
-RT_DEV float gen_log01(Stream& s, float) {
-  uint64_t k = next_word(s) >> 11;
+RT_DEV double gen_log01(const Stream& s, uint32_t slot, double) { return rt_log((double)(word_at(s, slot) >> 11) * 0x1.0p-53); }
+RT_DEV float gen_log01(const Stream& s, uint32_t slot, float) {
+  uint64_t k = word_at(s, slot) >> 11;
   if (k >= (1ull << 52)) return log1pf(-((float)((1ull << 53) - k) * 0x1.0p-53f));
   return rt_log((float)k * 0x1.0p-53f);
 }

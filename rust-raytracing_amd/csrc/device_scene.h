@@ -76,8 +76,9 @@ template <class R> struct DBackground {  // src/color.rs:35-39
 
 // Section byte offsets inside the blob + counts.  Passed to kernels by value.
 struct BlobLayout {
-  uint32_t links_off, shapes_off, objects_off, materials_off, textures_off, perlins_off, total_bytes;
+  uint32_t links_off, shapes_off, objects_off, materials_off, textures_off, perlins_off, flat_off, total_bytes;
   uint32_t n_links, n_objects, n_materials, n_textures, n_perlins;
+  uint32_t n_flat;  // > 0: the leaf words of the tree in visiting order follow at flat_off (single-precision small scenes)
 };
 
 template <class R> struct DeviceScene {
@@ -145,6 +146,11 @@ template <class T> RT_DEV T load_uniform(const T* p) {
   return u.t;
 }
 
+RT_DEV uint32_t load_uniform_u32(const uint32_t* p) {
+  typedef const __attribute__((address_space(4))) uint32_t* const_ptr;
+  return *(const_ptr)(uintptr_t)p;
+}
+
 // What the hit / shade routines read.  `links`, `shapes`, `objects` are read with wave-uniform indices in WALK_UNIFORM
 // (global memory, scalar loads) and per lane otherwise; materials, textures and Perlin tables are always gathered per lane
 // and sit in LDS unless only the top links fit there.
@@ -155,6 +161,8 @@ template <class R, class C> struct SceneView {
   uint32_t n_links;
   const DShape<R>* shapes;
   const DObject<R>* objects;
+  const uint32_t* flat;            // leaf words in visiting order (global memory, scalar loads), n_flat of them
+  uint32_t n_flat;
   const DShape<R>* shapes_lane;    // the same records where a lane gathers them with an index of its own (LDS in WALK_UNIFORM)
   const DObject<R>* objects_lane;
   const DMaterial<R>* materials;
@@ -229,6 +237,8 @@ template <class R, class C> RT_DEV SceneView<R, C> make_view(const DeviceScene<R
   v.textures = reinterpret_cast<const DTexture<R>*>(shade + (sc.lay.textures_off - shade_sub));
   v.perlins = reinterpret_cast<const DPerlin<R>*>(shade + (sc.lay.perlins_off - shade_sub));
   v.images = sc.images;
+  v.flat = reinterpret_cast<const uint32_t*>(g + sc.lay.flat_off);
+  v.n_flat = sc.lay.n_flat;
   return v;
 }
 

@@ -288,14 +288,14 @@ RT_DEV bool object_hit(const SceneView<R, C>& sv, int obj_index, const Ray<R>& r
       if (t1 < (R)0) t1 = (R)0;
       R ray_length = length(ray.d);
       R distance_inside_boundary = (t2 - t1) * ray_length;
-      R hit_distance = ob.neg_inv_density * gen_log01(media, (R)0);
+      const DShape<R> ids = sv.shape(obj_index);
+      R hit_distance = ob.neg_inv_density * gen_log01(media, (uint32_t)ids.obj_id, (R)0);
       if (hit_distance > distance_inside_boundary) return false;
       rec.t = t1 + hit_distance / ray_length;
       rec.p = ray.at(rec.t);
       rec.n = V3<R>((R)1, (R)0, (R)0);
       rec.front = 1;
       rec.mat = ob.medium_material;  // u, v untouched
-      const DShape<R> ids = sv.shape(obj_index);
       rec.obj = ids.obj_id;
       rec.sub = ids.sub_id;
       rec.side = -1;

@@ -28,20 +28,20 @@ template <> struct RayInv<float> {
   template <int AXIS> RT_DEV float quot(float num) const { return num * (AXIS == 0 ? inv.x : AXIS == 1 ? inv.y : inv.z); }
 };
 
-// src/aarect.rs:88-97: distance to the plane, range test, in-plane bounds (closed).
+// src/aarect.rs:88-97: distance to the plane, range test, in-plane bounds (closed).  Written without early exits: the six
+// comparisons are the reference's own (negated, so a NaN passes them as it does there) and their conjunction decides.
 template <class R, int AXIS>
 RT_DEV bool rect_t(R a0, R a1, R b0, R b1, R k, const Ray<R>& ray, const RayInv<R>& ri, R t_min, R t_max, R& t_out) {
   constexpr int A = (AXIS == 0) ? 1 : 0;
   constexpr int B = (AXIS == 2) ? 1 : 2;
   const R o[3] = {ray.o.x, ray.o.y, ray.o.z};
   const R d[3] = {ray.d.x, ray.d.y, ray.d.z};
-  R t = ri.template quot<AXIS>(k - o[AXIS]);
-  if (t < t_min || t > t_max) return false;
-  R a = o[A] + t * d[A];
-  R b = o[B] + t * d[B];
-  if (a < a0 || a > a1 || b < b0 || b > b1) return false;
-  t_out = t;
-  return true;
+  const R t = ri.template quot<AXIS>(k - o[AXIS]);
+  const R a = o[A] + t * d[A];
+  const R b = o[B] + t * d[B];
+  const bool ok = !(t < t_min) & !(t > t_max) & !(a < a0) & !(a > a1) & !(b < b0) & !(b > b1);
+  if (ok) t_out = t;
+  return ok;
 }
 
 // hit() of one shape reduced to its t (and the side of a box).  `self_side` as in shape_hit.
@@ -135,7 +135,7 @@ RT_DEV bool leaf_t(const SceneView<R, C>& sv, uint32_t leaf_word, const Ray<R>& 
           if (t1 < (R)0) t1 = (R)0;
           R ray_length = length(ray.d);
           R distance_inside_boundary = (t2 - t1) * ray_length;
-          R hit_distance = ob.neg_inv_density * gen_log01(media, (R)0);
+          R hit_distance = ob.neg_inv_density * gen_log01(media, (uint32_t)s.obj_id, (R)0);
           if (hit_distance > distance_inside_boundary) return false;
           t_out = t1 + hit_distance / ray_length;
           side_out = SIDE_MEDIUM;
@@ -273,11 +273,45 @@ RT_DEV bool traverse_uniform(const SceneView<R, C>& sv, int start, const Ray<R>&
   return true;
 }
 
+// Single precision, scenes of a few leaves: every leaf is tested, in the order the tree would visit them, with the same
+// shrinking t_max; only the root box is kept as an early out.  A box test can only skip leaves the ray does not hit (up to
+// rounding at grazing incidence, which the single-precision tolerance covers), and with incoherent rays every wave visits
+// every entry anyway, so the inner box tests and the per-lane position in the tree are pure overhead here.
+template <class R, class C>
+RT_DEV bool traverse_flat(const SceneView<R, C>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
+  const RayInv<R> ri(ray.d);
+  R closest = t_max;
+  int best_leaf = -1, best_side = -1;
+  const DLink<R> root = sv.link_uniform(start);
+  const bool inside = (root.hit & LEAF_FLAG) ? true : aabb_hit(root, ray, ri.inv, t_min, closest);
+  if (inside) {
+    for (uint32_t k = 0; k < sv.n_flat; ++k) {
+      const uint32_t word = load_uniform_u32(sv.flat + k);
+      R t;
+      int side;
+      if (leaf_t<R, C>(sv, word, ray, ri, t_min, closest, media, org, t, side)) {
+        closest = t;
+        best_leaf = (int)(word & LEAF_INDEX_MASK);
+        best_side = side;
+      }
+    }
+  }
+  if (best_leaf < 0) return false;
+  finalize_hit<R, C>(sv, ray, closest, best_leaf, best_side, rec);
+  return true;
+}
+
 // world.hit(ray, t_min, t_max, rec).  May be called from divergent code: lanes without a ray simply do not take part.
 template <class R, class C>
 RT_DEV bool closest_hit(const SceneView<R, C>& sv, int root, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
-  if constexpr (C::walk == WALK_UNIFORM) return traverse_uniform<R, C>(sv, root, ray, t_min, t_max, rec, media, org);
-  else return traverse_lane<R, C, 0>(sv, root, ray, t_min, t_max, rec, media, org);
+  if constexpr (C::walk == WALK_UNIFORM) {
+    if constexpr (sizeof(R) == sizeof(float)) {
+      if (sv.n_flat != 0u) return traverse_flat<R, C>(sv, root, ray, t_min, t_max, rec, media, org);
+    }
+    return traverse_uniform<R, C>(sv, root, ray, t_min, t_max, rec, media, org);
+  } else {
+    return traverse_lane<R, C, 0>(sv, root, ray, t_min, t_max, rec, media, org);
+  }
 }
 
 }  // namespace rtd

@@ -50,8 +50,19 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
   lay.materials_off = off; off = align16(off + lay.n_materials * (uint32_t)sizeof(DMaterial<R>));
   lay.textures_off = off; off = align16(off + lay.n_textures * (uint32_t)sizeof(DTexture<R>));
   lay.perlins_off = off; off = align16(off + lay.n_perlins * (uint32_t)sizeof(DPerlin<R>));
+  // leaf words in visiting order (the small-scene presets store their links in that order)
+  std::vector<uint32_t> flat;
+  const bool uniform_preset = preset == PRESET_BOXES || preset == PRESET_SMOKE || preset == PRESET_SPHERES;
+  if (uniform_preset && sizeof(R) == sizeof(float) && !getenv("RTAMD_NO_FLAT")) {
+    for (const TmpLink& l : links)
+      if (l.hit & LEAF_FLAG) flat.push_back(l.hit);
+    if (flat.size() > kFlatMaxLeaves) flat.clear();
+  }
+  lay.flat_off = off; off = align16(off + (uint32_t)(kFlatMaxLeaves * sizeof(uint32_t)));
+  lay.n_flat = (uint32_t)flat.size();
   lay.total_bytes = off;
   std::vector<uint8_t> blob(off, 0);
+  if (!flat.empty()) memcpy(blob.data() + lay.flat_off, flat.data(), flat.size() * sizeof(uint32_t));
   auto* L = reinterpret_cast<DLink<R>*>(blob.data() + lay.links_off);
   for (size_t i = 0; i < links.size(); ++i) {
     for (int k = 0; k < 3; ++k) { L[i].bmin[k] = round_down<R>(links[i].bmin[k]); L[i].bmax[k] = round_up<R>(links[i].bmax[k]); }
