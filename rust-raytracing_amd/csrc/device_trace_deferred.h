@@ -273,31 +273,115 @@ RT_DEV bool traverse_uniform(const SceneView<R, C>& sv, int start, const Ray<R>&
   return true;
 }
 
+// ---- single-precision forms used by the flat walk ----
+// x in [lo, hi] as one median and one compare; a NaN is outside.
+RT_DEV bool in_closed(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi) == x; }
+
+template <int AXIS>
+RT_DEV bool rect_fast(float a0, float a1, float b0, float b1, float k, const Ray<float>& ray, const RayInv<float>& ri, float t_min, float t_max,
+                      float& t_out) {
+  constexpr int A = (AXIS == 0) ? 1 : 0;
+  constexpr int B = (AXIS == 2) ? 1 : 2;
+  const float o[3] = {ray.o.x, ray.o.y, ray.o.z};
+  const float d[3] = {ray.d.x, ray.d.y, ray.d.z};
+  const float t = ri.template quot<AXIS>(k - o[AXIS]);
+  const float a = o[A] + t * d[A];
+  const float b = o[B] + t * d[B];
+  t_out = t;
+  return in_closed(t, t_min, t_max) & in_closed(a, a0, a1) & in_closed(b, b0, b1);
+}
+
+// The six sides of a box (src/box_struct.rs:22-71) as three slabs: the ray meets the surface where it enters (largest of the
+// per-axis near distances) and where it leaves (smallest far distance), provided enter <= leave; the closest of the two inside
+// [t_min, t_max] is what testing the six rectangles one by one returns.  Side numbering and tie order (a later side wins:
+// x sides over y sides over z sides) follow the reference's list.  `self_side` (>= 0) removes the side the ray starts on.
+RT_DEV bool box_slab_t(const DShape<float>& s, const Ray<float>& ray, const RayInv<float>& ri, float t_min, float t_max, int self_side,
+                       float& t_out, int& side_out) {
+  const float x0 = (s.p[0] - ray.o.x) * ri.inv.x, x1 = (s.p[3] - ray.o.x) * ri.inv.x;
+  const float y0 = (s.p[1] - ray.o.y) * ri.inv.y, y1 = (s.p[4] - ray.o.y) * ri.inv.y;
+  const float z0 = (s.p[2] - ray.o.z) * ri.inv.z, z1 = (s.p[5] - ray.o.z) * ri.inv.z;
+  const float nx = rt_min(x0, x1), fx = rt_max(x0, x1);
+  const float ny = rt_min(y0, y1), fy = rt_max(y0, y1);
+  const float nz = rt_min(z0, z1), fz = rt_max(z0, z1);
+  const float tn = rt_max(rt_max(nx, ny), nz);
+  const float tf = rt_min(rt_min(fx, fy), fz);
+  // sides: 0 z=hi, 1 z=lo, 2 y=hi, 3 y=lo, 4 x=hi, 5 x=lo; the near plane of an axis is lo when the ray moves up that axis
+  const int px = ray.d.x > 0.0f ? 1 : 0, py = ray.d.y > 0.0f ? 1 : 0, pz = ray.d.z > 0.0f ? 1 : 0;
+  const int near_side = nx == tn ? 4 + px : (ny == tn ? 2 + py : pz);
+  const int far_side = fx == tf ? 5 - px : (fy == tf ? 3 - py : 1 - pz);
+  const bool cross = tn <= tf;
+  const bool enter_ok = cross & in_closed(tn, t_min, t_max) & (near_side != self_side);
+  const bool leave_ok = cross & in_closed(tf, t_min, t_max) & (far_side != self_side);
+  t_out = enter_ok ? tn : tf;
+  side_out = enter_ok ? near_side : far_side;
+  return enter_ok | leave_ok;
+}
+
 // Single precision, scenes of a few leaves: every leaf is tested, in the order the tree would visit them, with the same
 // shrinking t_max; only the root box is kept as an early out.  A box test can only skip leaves the ray does not hit (up to
 // rounding at grazing incidence, which the single-precision tolerance covers), and with incoherent rays every wave visits
 // every entry anyway, so the inner box tests and the per-lane position in the tree are pure overhead here.
-template <class R, class C>
-RT_DEV bool traverse_flat(const SceneView<R, C>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
-  const RayInv<R> ri(ray.d);
-  R closest = t_max;
+template <class C>
+RT_DEV bool traverse_flat(const SceneView<float, C>& sv, int start, const Ray<float>& ray, float t_min, float t_max, Rec<float>& rec, Stream& media,
+                          Origin org) {
+  const RayInv<float> ri(ray.d);
+  float closest = t_max;
   int best_leaf = -1, best_side = -1;
-  const DLink<R> root = sv.link_uniform(start);
+  const DLink<float> root = sv.link_uniform(start);
   const bool inside = (root.hit & LEAF_FLAG) ? true : aabb_hit(root, ray, ri.inv, t_min, closest);
   if (inside) {
+    const int org_leaf = org.leaf(), org_side = org.side();
     for (uint32_t k = 0; k < sv.n_flat; ++k) {
       const uint32_t word = load_uniform_u32(sv.flat + k);
-      R t;
-      int side;
-      if (leaf_t<R, C>(sv, word, ray, ri, t_min, closest, media, org, t, side)) {
-        closest = t;
-        best_leaf = (int)(word & LEAF_INDEX_MASK);
-        best_side = side;
+      const int obj = (int)(word & LEAF_INDEX_MASK);
+      const DShape<float> s = sv.shape(obj);
+      const bool self = org_leaf == obj;
+      float t = 0.0f;
+      int side = -1;
+      bool ok = false;
+      bool plain = (word & LEAF_SIMPLE) != 0u;
+      Ray<float> local = ray;
+      RayInv<float> rl = ri;
+      if constexpr (C::has(F_XFORM) || C::has(F_MEDIUM)) {
+        if (!plain) {
+          const DObject<float> ob = sv.object(obj);
+          bool medium = false;
+          if constexpr (C::has(F_MEDIUM)) medium = (ob.flags & OBJ_MEDIUM) != 0u;
+          if (medium) {
+            ok = leaf_t<float, C>(sv, word, ray, ri, t_min, closest, media, org, t, side);
+          } else {
+            Ray<float> moved;
+            to_local(ob, ray, moved, local);
+            if (ob.flags & OBJ_ROTATE_Y) {  // the y component of the direction is unchanged
+              rl.inv.x = __builtin_amdgcn_rcpf(local.d.x);
+              rl.inv.z = __builtin_amdgcn_rcpf(local.d.z);
+            }
+            plain = true;
+          }
+        }
       }
+      if (plain) {
+        switch (s.tag) {
+          case SH_SPHERE: if constexpr (C::has(F_SPHERE)) {
+            ok = sphere_roots(V3<float>(s.p[0], s.p[1], s.p[2]), local, s.p[3], t_min, closest, t, self);
+          } break;
+          case SH_MOVING: if constexpr (C::has(F_MOVING)) {
+            ok = sphere_roots(moving_center(s, local.time), local, s.p[6], t_min, closest, t, self);
+          } break;
+          case SH_RECT_XY: if constexpr (C::has(F_RECT)) { ok = rect_fast<2>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], local, rl, t_min, closest, t) & !self; } break;
+          case SH_RECT_XZ: if constexpr (C::has(F_RECT)) { ok = rect_fast<1>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], local, rl, t_min, closest, t) & !self; } break;
+          case SH_RECT_YZ: if constexpr (C::has(F_RECT)) { ok = rect_fast<0>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], local, rl, t_min, closest, t) & !self; } break;
+          case SH_BOX: if constexpr (C::has(F_BOX)) { ok = box_slab_t(s, local, rl, t_min, closest, self ? org_side : -2, t, side); } break;
+          default: break;
+        }
+      }
+      closest = ok ? t : closest;
+      best_leaf = ok ? obj : best_leaf;
+      best_side = ok ? side : best_side;
     }
   }
   if (best_leaf < 0) return false;
-  finalize_hit<R, C>(sv, ray, closest, best_leaf, best_side, rec);
+  finalize_hit<float, C>(sv, ray, closest, best_leaf, best_side, rec);
   return true;
 }
 
@@ -306,7 +390,7 @@ template <class R, class C>
 RT_DEV bool closest_hit(const SceneView<R, C>& sv, int root, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
   if constexpr (C::walk == WALK_UNIFORM) {
     if constexpr (sizeof(R) == sizeof(float)) {
-      if (sv.n_flat != 0u) return traverse_flat<R, C>(sv, root, ray, t_min, t_max, rec, media, org);
+      if (sv.n_flat != 0u) return traverse_flat<C>(sv, root, ray, t_min, t_max, rec, media, org);
     }
     return traverse_uniform<R, C>(sv, root, ray, t_min, t_max, rec, media, org);
   } else {
