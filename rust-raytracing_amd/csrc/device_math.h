@@ -196,7 +196,13 @@ RT_DEV V3<double> random_in_unit_sphere(const Stream& s, double) {
   }
 }
 template <class R> RT_DEV V3<R> random_in_unit_sphere(const Stream& s) { return random_in_unit_sphere(s, (R)0); }
-template <class R> RT_DEV V3<R> random_unit_vector(const Stream& s) { return unit_vector(random_in_unit_sphere<R>(s)); }  // src/vec3.rs:90-92
+// src/vec3.rs:90-92.  Single precision scales by the hardware reciprocal square root (1 ulp) instead of sqrt then divide.
+RT_DEV V3<double> random_unit_vector(const Stream& s, double) { return unit_vector(random_in_unit_sphere<double>(s)); }
+RT_DEV V3<float> random_unit_vector(const Stream& s, float) {
+  V3<float> p = random_in_unit_sphere<float>(s);
+  return __builtin_amdgcn_rsqf(length_squared(p)) * p;
+}
+template <class R> RT_DEV V3<R> random_unit_vector(const Stream& s) { return random_unit_vector(s, (R)0); }
 // src/vec3.rs:103-111 on the camera stream: candidate c is block 1 + c.
 template <class R> RT_DEV V3<R> random_in_unit_disk(const Stream& s) {
   for (uint32_t c = 0;; ++c) {

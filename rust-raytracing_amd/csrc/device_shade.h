@@ -146,17 +146,36 @@ template <class R, class C> RT_DEV V3<R> background_color(const DBackground<R>& 
   return ((R)1 - t) * bg.c1 + t * bg.c0;
 }
 
+// Row and column of a pixel index without an integer division: a float reciprocal estimate corrected by one step is exact
+// while the index is exactly representable (images below 2^24 pixels); larger images divide.
+RT_DEV void pixel_row_col(uint32_t pixel, uint32_t W, uint32_t& y, uint32_t& i) {
+  if (pixel < (1u << 24)) {
+    uint32_t q = (uint32_t)((float)pixel * __builtin_amdgcn_rcpf((float)W));
+    int32_t r = (int32_t)(pixel - q * W);
+    if (r < 0) { q -= 1u; r += (int32_t)W; }
+    if (r >= (int32_t)W) { q += 1u; r -= (int32_t)W; }
+    y = q; i = (uint32_t)r;
+  } else {
+    y = pixel / W; i = pixel - y * W;
+  }
+}
+// (i + u) / (W - 1), src/render.rs:232-233.  Single precision multiplies by the reciprocal (wave-uniform, one rounding more).
+RT_DEV double jitter_coord(uint32_t i, double u, uint32_t wm1) { return ((double)i + u) / (double)wm1; }
+RT_DEV float jitter_coord(uint32_t i, float u, uint32_t wm1) { return ((float)i + u) * (1.0f / (float)wm1); }
+
 // Primary ray of (pixel, sample): src/render.rs:230-234 then Camera::get_ray (src/camera.rs:62-72).
 // pixel = y * W + x with y counted from the top row; the reference's j is H - 1 - y.
 template <class R>
 RT_DEV Ray<R> primary_ray(const DCamera<R>& cam, uint32_t W, uint32_t H, uint32_t pixel, uint32_t sample, uint64_t seed) {
-  uint32_t y = pixel / W, i = pixel - y * W, j = H - 1u - y;
+  uint32_t y, i;
+  pixel_row_col(pixel, W, y, i);
+  uint32_t j = H - 1u - y;
   const Stream rng(seed, pixel, sample, 0u, STAGE_CAMERA);
   const Block<R> jitter(rng, 0u);
   R u_rand = jitter.u01(0);
   R v_rand = jitter.u01(1);
-  R s = ((R)i + u_rand) / (R)(W - 1u);
-  R t = ((R)j + v_rand) / (R)(H - 1u);
+  R s = jitter_coord(i, u_rand, W - 1u);
+  R t = jitter_coord(j, v_rand, H - 1u);
   // a pinhole camera (lens_radius == 0) multiplies the disk sample by zero; draws are addressed, so skipping it moves nothing else
   V3<R> rd((R)0, (R)0, (R)0);
   if (cam.lens_radius != (R)0) rd = cam.lens_radius * random_in_unit_disk<R>(rng);

@@ -239,8 +239,10 @@ __global__ __launch_bounds__(256) void k_paths_persistent(DeviceScene<R> sc, Fra
   extern __shared__ __align__(16) uint8_t lds[];
   const SceneView<R, C> sv = make_view<R, C>(sc, lds);
   const uint32_t lane = threadIdx.x & 63u;
-  unsigned long long grab_next = 0, grab_end = 0;  // wave-uniform: unstarted path indices this wave owns
-  bool exhausted = false;                          // wave-uniform: the cursor has passed total_paths
+  // wave-uniform: the unstarted paths this wave owns are `grab_left` consecutive ones starting at pixel grab_pixel of sample
+  // grab_sample (path index = sample * n_pixels + pixel, kept as the pair so that no lane ever divides)
+  uint32_t grab_left = 0, grab_pixel = 0, grab_sample = 0;
+  bool exhausted = false;  // wave-uniform: the cursor has passed total_paths
   bool active = false;
   uint32_t bounce = 0;
   unsigned long long n_rays = 0;
@@ -250,32 +252,35 @@ __global__ __launch_bounds__(256) void k_paths_persistent(DeviceScene<R> sc, Fra
     RT_STAMP(6);
     unsigned long long dead = __ballot(!active);
     while (dead != 0ull && !exhausted) {
-      if (grab_next == grab_end) {
+      if (grab_left == 0u) {
         unsigned long long b = 0;
         if (lane == 0u) b = atomicAdd(path_cursor, (unsigned long long)kPathGrab);
         uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
         uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
         b = ((unsigned long long)hi << 32) | lo;
         if (b >= total_paths) { exhausted = true; break; }
-        grab_next = b;
-        grab_end = b + kPathGrab < total_paths ? b + kPathGrab : total_paths;
+        const unsigned long long e = b + kPathGrab < total_paths ? b + kPathGrab : total_paths;
+        grab_left = (uint32_t)(e - b);
+        grab_sample = (uint32_t)(b / fp.n_pixels);
+        grab_pixel = (uint32_t)(b - (unsigned long long)grab_sample * fp.n_pixels);
       }
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
       const uint32_t n_dead = (uint32_t)__popcll(dead);
-      const unsigned long long avail = grab_end - grab_next;
-      const uint32_t n_take = avail < (unsigned long long)n_dead ? (uint32_t)avail : n_dead;
+      uint32_t n_take = grab_left < n_dead ? grab_left : n_dead;
+      const uint32_t row_left = fp.n_pixels - grab_pixel;  // do not run past the end of a sample in one step
+      n_take = n_take < row_left ? n_take : row_left;
       if (!active && rank < n_take) {
-        const unsigned long long path = grab_next + rank;
-        const uint32_t s = (uint32_t)(path / fp.n_pixels);
-        st.pixel = (uint32_t)(path - (unsigned long long)s * fp.n_pixels);
-        st.sample = fp.sample_base + s;
+        st.pixel = grab_pixel + rank;
+        st.sample = fp.sample_base + grab_sample;
         st.ray = primary_ray<R>(sc.camera, fp.width, fp.height, st.pixel, st.sample, fp.seed);
         st.thr = V3<R>((R)1, (R)1, (R)1);
         st.org = Origin();
         bounce = 0;
         active = true;
       }
-      grab_next += n_take;
+      grab_left -= n_take;
+      grab_pixel += n_take;
+      if (grab_pixel == fp.n_pixels) { grab_pixel = 0u; grab_sample += 1u; }
       dead = __ballot(!active);
     }
     RT_STAMP(0);
