@@ -103,6 +103,10 @@ enum : uint32_t { STAGE_CAMERA = 0, STAGE_MEDIA = 1, STAGE_SCATTER = 2 };
 // A rejection loop reads "the first candidate c = 0, 1, 2, ... that is accepted" (src/vec3.rs:81-88,103-111).
 // The float build uses the top 24 / 23 bits of a word, so it needs H only and it sees the same numbers, rounded, as the double build.
 struct Stream {
+#ifdef RT_STAMPS
+  unsigned long long* stamp_acc = nullptr;  // diagnostic build: the kernel's phase accumulators, reachable from the hit routines
+  unsigned long long* stamp_t = nullptr;
+#endif
   uint32_t k0, k1, c1, c2, c3;
   RT_DEV Stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t stage)
       : k0(pixel), k1(sample), c1(bounce | (stage << 16)), c2((uint32_t)seed), c3((uint32_t)(seed >> 32)) {}

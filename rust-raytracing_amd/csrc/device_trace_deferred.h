@@ -10,6 +10,20 @@
 #pragma once
 #include "device_trace.h"
 
+#ifdef RT_STAMPS
+#define RT_STAMP_IN(stream, k)                                             \
+  do {                                                                     \
+    if ((stream).stamp_acc) {                                              \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          \
+      unsigned long long now_ = __builtin_amdgcn_s_memtime();              \
+      (stream).stamp_acc[k] += now_ - *(stream).stamp_t;                   \
+      *(stream).stamp_t = now_;                                            \
+    }                                                                      \
+  } while (0)
+#else
+#define RT_STAMP_IN(stream, k) do {} while (0)
+#endif
+
 namespace rtd {
 
 constexpr int SIDE_MEDIUM = 6;  // candidate produced by a ConstantMedium (sides -1..5 are surfaces)
@@ -329,6 +343,7 @@ RT_DEV bool traverse_flat(const SceneView<float, C>& sv, int start, const Ray<fl
   int best_leaf = -1, best_side = -1;
   const DLink<float> root = sv.link_uniform(start);
   const bool inside = (root.hit & LEAF_FLAG) ? true : aabb_hit(root, ray, ri.inv, t_min, closest);
+  RT_STAMP_IN(media, 3);
   if (inside) {
     const int org_leaf = org.leaf(), org_side = org.side();
     for (uint32_t k = 0; k < sv.n_flat; ++k) {
@@ -380,8 +395,10 @@ RT_DEV bool traverse_flat(const SceneView<float, C>& sv, int start, const Ray<fl
       best_side = ok ? side : best_side;
     }
   }
+  RT_STAMP_IN(media, 4);
   if (best_leaf < 0) return false;
   finalize_hit<float, C>(sv, ray, closest, best_leaf, best_side, rec);
+  RT_STAMP_IN(media, 5);
   return true;
 }
 

@@ -96,7 +96,9 @@ template <class R> RT_DEV void add_radiance(R* accum, uint32_t pixel, V3<R> c) {
       for (int k_ = 0; k_ < 8; ++k_) slot_[k_] += stamp_acc[k_];           \
     }                                                                      \
   } while (0)
+#define RT_STAMP_ATTACH(stream) do { (stream).stamp_acc = stamp_acc; (stream).stamp_t = &stamp_t; } while (0)
 #else
+#define RT_STAMP_ATTACH(stream) do {} while (0)
 #define RT_STAMP_INIT() do {} while (0)
 #define RT_STAMP(k) do {} while (0)
 #define RT_STAMP_FLUSH(base) do {} while (0)
@@ -291,6 +293,7 @@ __global__ __launch_bounds__(256) void k_paths_persistent(DeviceScene<R> sc, Fra
     Rec<R> rec;
     if (active) {
       Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
+      RT_STAMP_ATTACH(media);
       hit = closest_hit<R, C>(sv, sc.root_link, st.ray, (R)0.001, Lim<R>::inf(), rec, media, st.org);
     }
     RT_STAMP(1);

@@ -190,7 +190,7 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
       for (size_t w = 16; w + 8 <= kRayCountWords; w += 8)
         for (int k = 0; k < 8; ++k) st[k] += (double)all[w + k];
       for (int k = 0; k < 8; ++k) tot += st[k];
-      fprintf(stderr, "[stamps] persistent, wave cycles by phase (refill, trace, shade+accumulate, ., ., ., loop top):");
+      fprintf(stderr, "[stamps] persistent, wave cycles by phase (refill, trace rest, shade+accumulate, walk setup + root box, leaf loop, finalize, loop top):");
       for (int k = 0; k < 7; ++k) fprintf(stderr, " %.1f%%", 100.0 * st[k] / tot);
       fprintf(stderr, "  %.0f cycles per wave iteration of %.1f rays\n", tot / ((double)rays / 64.0) , 64.0);
     }
