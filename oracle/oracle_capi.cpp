@@ -489,15 +489,35 @@ double orc_render(const orc_scene* s, uint32_t s_begin, uint32_t s_end, uint64_t
 }
 int orc_counters_len(void) { return (int)(sizeof(Counters) / sizeof(uint64_t)); }
 
-// Per-sample radiance for selected (pixel, sample) pairs: 3 doubles each.
+// Per-sample radiance for selected (pixel, sample) pairs: 4 doubles each = r, g, b, closest-hit queries of the path.
 void orc_sample_radiance(const orc_scene* s, uint64_t seed, size_t n, const uint32_t* pixel, const uint32_t* sample, double* out) {
   const auto& sc = *s->d;
   uint32_t W = sc.width(), H = sc.height();
   for (size_t r = 0; r < n; ++r) {
     uint32_t y = pixel[r] / W, i = pixel[r] % W, j = H - 1 - y;
+    const uint64_t rays_before = g_cnt.rays;
     V3<double> c = sample_radiance<double>(sc, W, H, i, j, sample[r], seed);
-    out[r * 3] = c[0]; out[r * 3 + 1] = c[1]; out[r * 3 + 2] = c[2];
+    out[r * 4] = c[0]; out[r * 4 + 1] = c[1]; out[r * 4 + 2] = c[2]; out[r * 4 + 3] = (double)(g_cnt.rays - rays_before);
   }
+}
+
+// The closest-hit queries of one path: up to max_vertices records of 11 doubles (origin[3], direction[3], t, obj, sub, hit,
+// front_face); returns how many the path made.
+int orc_sample_path(const orc_scene* s, uint64_t seed, uint32_t pixel, uint32_t sample, int max_vertices, double* out) {
+  const auto& sc = *s->d;
+  uint32_t W = sc.width(), H = sc.height();
+  std::vector<PathVertex> trace;
+  g_path_trace = &trace;
+  uint32_t y = pixel / W, i = pixel % W, j = H - 1 - y;
+  (void)sample_radiance<double>(sc, W, H, i, j, sample, seed);
+  g_path_trace = nullptr;
+  for (int k = 0; k < max_vertices && k < (int)trace.size(); ++k) {
+    const PathVertex& v = trace[k];
+    double* o = out + (size_t)k * 11;
+    for (int a = 0; a < 3; ++a) { o[a] = v.o[a]; o[3 + a] = v.d[a]; }
+    o[6] = v.t; o[7] = v.obj; o[8] = v.sub; o[9] = v.hit; o[10] = v.front;
+  }
+  return (int)trace.size();
 }
 
 // color.rs:14-27 over a whole accumulation buffer.

@@ -90,8 +90,11 @@ enum Stage : uint32_t { STAGE_CAMERA = 0, STAGE_MEDIA = 1, STAGE_SCATTER = 2 };
 // evaluation only ever needs H.)  Slot assignment per stage:
 //   CAMERA   slot 0 = pixel jitter u, 1 = jitter v, 2 = shutter time;
 //            lens-disk candidate c uses slots 4(1+c), 4(1+c)+1
-//   SCATTER  unit-sphere candidate c uses slots 4c, 4c+1, 4c+2 (Lambertian,
-//            Metal fuzz, Isotropic); Dielectric's one uniform is slot 0
+//   SCATTER  unit-sphere candidate c (Lambertian, Metal fuzz, Isotropic) takes
+//            two words (w0, w1) of H block c>>1 - words 0,1 for even c, 2,3 for
+//            odd c - cut into three 21-bit fields, and words 0..2 of L block c
+//            for the 31 low bits of each coordinate (52-bit mantissas, the
+//            resolution of rand's gen_range); Dielectric's one uniform is slot 0
 //   MEDIA    the free-path draw of ConstantMedium object k is slot k (one
 //            draw per object and ray, whatever order the tree visits them in)
 // The rejection loops of vec3.rs:81-88,103-111 therefore read "the first
@@ -106,6 +109,14 @@ struct Stream {
     key[0] = pixel; key[1] = sample;
     c1 = bounce | ((uint32_t)st << 16);
     c2 = (uint32_t)seed; c3 = (uint32_t)(seed >> 32);
+  }
+  void hi_block(uint32_t b, uint32_t out[4]) const {
+    uint32_t c[4] = {b, c1, c2, c3};
+    philox4x32_10(c, key, out);
+  }
+  void lo_block(uint32_t b, uint32_t out[4]) const {
+    uint32_t c[4] = {b, c1 | (1u << 20), c2, c3};
+    philox4x32_10(c, key, out);
   }
   uint64_t word(uint32_t slot) {
     uint32_t b = slot >> 2, j = slot & 3u;
@@ -177,12 +188,22 @@ template <class R> inline V3<R> operator/(const V3<R>& v, R f) { return ((R)1 / 
 template <class R> inline V3<R> operator-(const V3<R>& v) { return {-v.e[0], -v.e[1], -v.e[2]}; }
 template <class R> inline V3<R> unit_vector(const V3<R>& v) { return v / v.length(); }                         // vec3.rs:77-79
 
-template <class R> inline V3<R> random_in_unit_sphere(Stream& s) {  // vec3.rs:81-88 over vec3.rs:24-31; candidate c = block c
+// Coordinate in [-1, 1) from a 21-bit high field and a 31-bit low field: gen_range(-1.0..1.0) on the 52-bit mantissa
+// hi << 31 | lo (vec3.rs:24-31).  A float keeps the high field only.
+inline double coord_of(uint32_t hi21, uint32_t lo31, double) {
+  uint64_t m = ((uint64_t)hi21 << 31) | lo31;
+  return ((double)m * (1.0 / 4503599627370496.0)) * 2.0 + -1.0;
+}
+inline float coord_of(uint32_t hi21, uint32_t, float) { return (float)hi21 * (1.0f / 1048576.0f) - 1.0f; }
+template <class R> inline V3<R> random_in_unit_sphere(Stream& s) {  // vec3.rs:81-88: first candidate c = 0, 1, 2, ... inside the unit ball
+  uint32_t h[4] = {0, 0, 0, 0}, l[4];
   for (uint32_t c = 0;; ++c) {
-    R a = gen_range_at<R>(s, 4 * c + 0, (R)-1, (R)1);
-    R b = gen_range_at<R>(s, 4 * c + 1, (R)-1, (R)1);
-    R d = gen_range_at<R>(s, 4 * c + 2, (R)-1, (R)1);
-    V3<R> p(a, b, d);
+    if ((c & 1u) == 0) s.hi_block(c >> 1, h);
+    s.lo_block(c, l);
+    g_cnt.rng_words += 3;
+    uint32_t w0 = (c & 1u) ? h[2] : h[0], w1 = (c & 1u) ? h[3] : h[1];
+    uint32_t xi = w0 >> 11, yi = ((w0 & 0x7FFu) << 10) | (w1 >> 22), zi = (w1 >> 1) & 0x1FFFFFu;
+    V3<R> p(coord_of(xi, l[0] >> 1, (R)0), coord_of(yi, l[1] >> 1, (R)0), coord_of(zi, l[2] >> 1, (R)0));
     if (p.length_squared() < (R)1) return p;
   }
 }
@@ -932,6 +953,12 @@ struct PathKey {
   uint64_t seed;
   uint32_t pixel, sample;
 };
+// Optional trace of one path (test instrumentation): every closest-hit query appends its ray and what it found.
+struct PathVertex {
+  double o[3], d[3], t;
+  int obj, sub, hit, front;
+};
+inline thread_local std::vector<PathVertex>* g_path_trace = nullptr;
 template <class R>
 V3<R> ray_color(const Ray<R>& ray, const Background<R>& bg, const Hittable<R>& world, uint32_t depth, uint32_t max_depth, const PathKey& k) {
   if (depth == 0) { ++g_cnt.depth_exhausted; return V3<R>(); }
@@ -940,7 +967,14 @@ V3<R> ray_color(const Ray<R>& ray, const Background<R>& bg, const Hittable<R>& w
   Stream media(k.seed, k.pixel, k.sample, bounce, STAGE_MEDIA);
   HitCtx ctx{&media};
   HitRecord<R> rec;
-  if (!world.hit(ray, (R)0.001, std::numeric_limits<R>::infinity(), rec, ctx)) return bg.color(ray.direction);
+  const bool was_hit = world.hit(ray, (R)0.001, std::numeric_limits<R>::infinity(), rec, ctx);
+  if (g_path_trace) {
+    PathVertex v{{(double)ray.origin[0], (double)ray.origin[1], (double)ray.origin[2]},
+                 {(double)ray.direction[0], (double)ray.direction[1], (double)ray.direction[2]},
+                 was_hit ? (double)rec.t : 0.0, was_hit ? rec.obj : -1, was_hit ? rec.sub : -1, was_hit ? 1 : 0, was_hit && rec.front_face ? 1 : 0};
+    g_path_trace->push_back(v);
+  }
+  if (!was_hit) return bg.color(ray.direction);
   V3<R> emitted = rec.material->emitted(rec.u, rec.v, rec.p);
   Stream sc(k.seed, k.pixel, k.sample, bounce, STAGE_SCATTER);
   auto res = rec.material->scatter(ray, rec, sc);

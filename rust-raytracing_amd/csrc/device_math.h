@@ -98,7 +98,8 @@ enum : uint32_t { STAGE_CAMERA = 0, STAGE_MEDIA = 1, STAGE_SCATTER = 2 };
 // seed_lo, seed_hi).  Draws are addressed, not consumed in sequence: draw slot s is the 64-bit word H[s & 3] << 32 | L[s & 3],
 // H = block s >> 2 with half = 0, L = the same block with half = 1.  Slots by stage:
 //   CAMERA   0 = pixel jitter u, 1 = jitter v, 2 = shutter time; lens-disk candidate c = slots 4(1+c), 4(1+c)+1
-//   SCATTER  unit-sphere candidate c = slots 4c, 4c+1, 4c+2; the dielectric's uniform = slot 0
+//   SCATTER  unit-sphere candidate c = two words of H block c >> 1 (words 0,1 for even c, 2,3 for odd c) cut into three 21-bit
+//            fields + the top 31 bits of words 0..2 of L block c (52-bit mantissas); the dielectric's uniform = slot 0
 //   MEDIA    the free-path draw of ConstantMedium object k = slot k (independent of the order the tree visits objects in)
 // A rejection loop reads "the first candidate c = 0, 1, 2, ... that is accepted" (src/vec3.rs:81-88,103-111).
 // The float build uses the top 24 / 23 bits of a word, so it needs H only and it sees the same numbers, rounded, as the double build.
@@ -165,36 +166,54 @@ RT_DEV float gen_log01(const Stream& s, uint32_t slot, float) {
 }
 
 // src/vec3.rs:81-88: first candidate (three draws in [-1,1)) inside the unit ball; candidate c is block c of the stream.
+// src/vec3.rs:81-88: first candidate (a point of [-1,1)^3) inside the unit ball.  One Philox block of high halves serves two
+// candidates: its words (0,1) and (2,3) are each cut into three 21-bit coordinates.
+RT_DEV void fields21(uint32_t w0, uint32_t w1, uint32_t& xi, uint32_t& yi, uint32_t& zi) {
+  xi = w0 >> 11; yi = ((w0 & 0x7FFu) << 10) | (w1 >> 22); zi = (w1 >> 1) & 0x1FFFFFu;
+}
+RT_DEV float coord_of(uint32_t hi21, uint32_t, float) { return (float)hi21 * 0x1.0p-20f - 1.0f; }
+RT_DEV double coord_of(uint32_t hi21, uint32_t lo31, double) {  // gen_range(-1.0..1.0) on the 52-bit mantissa hi << 31 | lo
+  return ((double)(((uint64_t)hi21 << 31) | lo31) * 0x1.0p-52) * 2.0 + -1.0;
+}
+template <class R> RT_DEV V3<R> point_of(uint32_t w0, uint32_t w1, uint32_t l0, uint32_t l1, uint32_t l2) {
+  uint32_t xi, yi, zi;
+  fields21(w0, w1, xi, yi, zi);
+  return V3<R>(coord_of(xi, l0 >> 1, (R)0), coord_of(yi, l1 >> 1, (R)0), coord_of(zi, l2 >> 1, (R)0));
+}
 RT_DEV V3<float> random_in_unit_sphere(const Stream& s, float) {
 #ifdef RT_X_BOUND
-  for (uint32_t c = 0; c < 64u; ++c) {
+  for (uint32_t b = 0; b < 32u; ++b) {
 #else
-  for (uint32_t c = 0;; ++c) {
+  for (uint32_t b = 0;; ++b) {
 #endif
     uint32_t h[4];
-    s.hi(c, h);
-    V3<float> p(signed_unit_of<float>(h[0], 0u), signed_unit_of<float>(h[1], 0u), signed_unit_of<float>(h[2], 0u));
+    s.hi(b, h);
+    V3<float> p = point_of<float>(h[0], h[1], 0u, 0u, 0u);
 #ifdef RT_X_NOREJECT
     return p;
 #endif
     if (length_squared(p) < 1.0f) return p;
+    p = point_of<float>(h[2], h[3], 0u, 0u, 0u);
+    if (length_squared(p) < 1.0f) return p;
   }
   return V3<float>(0.5f, 0.0f, 0.0f);
 }
-// Double build: the high halves alone decide all but a sliver of candidates (the low halves move a coordinate by less than
-// 2^-31, the squared length by less than 2.8e-9), so the low block is fetched once, for the candidate that passes that test.
+// Double build: the high fields alone decide all but a sliver of candidates (the low fields move a coordinate by less than
+// 2^-20, the squared length by less than 5.8e-6), so the low block is fetched once, for the candidate that passes that test.
 RT_DEV V3<double> random_in_unit_sphere(const Stream& s, double) {
   uint32_t c = 0;
+  uint32_t h[4] = {0u, 0u, 0u, 0u};
   for (;;) {
-    uint32_t h[4];
+    uint32_t w0, w1;
     for (;; ++c) {
-      s.hi(c, h);
-      V3<double> q(signed_unit_of<double>(h[0], 0u), signed_unit_of<double>(h[1], 0u), signed_unit_of<double>(h[2], 0u));
-      if (length_squared(q) < 1.0 + 4e-9) break;
+      if ((c & 1u) == 0u) s.hi(c >> 1, h);
+      w0 = (c & 1u) ? h[2] : h[0];
+      w1 = (c & 1u) ? h[3] : h[1];
+      if (length_squared(point_of<double>(w0, w1, 0u, 0u, 0u)) < 1.0 + 6e-6) break;
     }
     uint32_t l[4];
     s.lo(c, l);
-    V3<double> p(signed_unit_of<double>(h[0], l[0]), signed_unit_of<double>(h[1], l[1]), signed_unit_of<double>(h[2], l[2]));
+    V3<double> p = point_of<double>(w0, w1, l[0], l[1], l[2]);
     if (length_squared(p) < 1.0) return p;
     ++c;
   }

@@ -166,9 +166,16 @@ class OracleScene:
     def sample_radiance(self, seed, pixel, sample):
         pixel = np.ascontiguousarray(pixel, dtype=np.uint32)
         sample = np.ascontiguousarray(sample, dtype=np.uint32)
-        out = np.zeros((pixel.size, 3))
+        out = np.zeros((pixel.size, 4))  # r, g, b, closest-hit queries of the path
         lib().orc_sample_radiance(self.h, seed, pixel.size, _p(pixel), _p(sample), _p(out))
         return out
+
+    def sample_path(self, seed, pixel, sample, max_vertices=64):
+        """Closest-hit queries of one path: rows of (origin[3], direction[3], t, obj, sub, hit, front_face)."""
+        out = np.zeros((max_vertices, 11))
+        lib().orc_sample_path.restype = C.c_int
+        n = lib().orc_sample_path(C.c_void_p(self.h), C.c_uint64(seed), C.c_uint32(int(pixel)), C.c_uint32(int(sample)), C.c_int(max_vertices), _p(out))
+        return out[:min(n, max_vertices)]
 
     def texture_value(self, material, u, v, p):
         p = np.ascontiguousarray(p, dtype=np.float64)

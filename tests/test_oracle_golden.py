@@ -194,4 +194,4 @@ def test_oracle_sample_range_additivity(oracle):
     px = np.array([5, 100, 2000], dtype=np.uint32)
     sm = np.array([0, 3, 5], dtype=np.uint32)
     rad = s.sample_radiance(3, px, sm)
-    assert rad.shape == (3, 3) and np.isfinite(rad).all()
+    assert rad.shape == (3, 4) and np.isfinite(rad).all() and (rad[:, 3] >= 1).all()
