@@ -51,11 +51,12 @@ def main():
     write = sum(t.get("WRITE_SIZE", 0.0) for t in tot.values()) * 1024.0
     out["hbm_bytes_per_frame"] = {"fetch_corrected": fetch, "write": write, "total": fetch + write}
     for kern, t in tot.items():
-        if t.get("SQ_ACTIVE_INST_VALU") and t.get("GRBM_GUI_ACTIVE"):
-            # SQ_ACTIVE_INST_* count quad-cycles summed over waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs
-            simd_cycles = t["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
-            t["valu_busy_frac"] = 4.0 * t["SQ_ACTIVE_INST_VALU"] / simd_cycles
-            t["clock_ghz"] = t["GRBM_GUI_ACTIVE"] / 8.0 / t["duration_ns"]
+        if t.get("SQ_INSTS_VALU") and t.get("GRBM_GUI_ACTIVE"):
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 256 CUs x 4 SIMDs issue vector instructions
+            cycles = t["GRBM_GUI_ACTIVE"] / 8.0
+            t["valu_insts_per_simd_cycle"] = t["SQ_INSTS_VALU"] / (1024.0 * cycles)
+            t["salu_insts_per_cu_cycle"] = t.get("SQ_INSTS_SALU", 0.0) / (256.0 * cycles)
+            t["clock_ghz"] = cycles / t["duration_ns"]
         if t.get("SQ_THREAD_CYCLES_VALU") and t.get("SQ_ACTIVE_INST_VALU"):
             t["lanes_active_per_valu_cycle"] = t["SQ_THREAD_CYCLES_VALU"] / t["SQ_ACTIVE_INST_VALU"]
     with open(os.path.join(dst, tag + "_pmc.json"), "w") as f:
@@ -68,7 +69,7 @@ def main():
     traffic[key] = {"bytes_per_frame": fetch + write, "spp": spp, "fetch_corrected": fetch, "write": write, "from": tag}
     with open(tp, "w") as f:
         json.dump(traffic, f, indent=1, sort_keys=True)
-    print(json.dumps(out["hbm_bytes_per_frame"]), {k: {m: v for m, v in t.items() if m in ("valu_busy_frac", "clock_ghz", "lanes_active_per_valu_cycle", "duration_ns")} for k, t in tot.items()})
+    print(json.dumps(out["hbm_bytes_per_frame"]), {k: {m: v for m, v in t.items() if m in ("valu_insts_per_simd_cycle", "salu_insts_per_cu_cycle", "clock_ghz", "lanes_active_per_valu_cycle", "duration_ns")} for k, t in tot.items()})
 
 
 if __name__ == "__main__":
