@@ -331,6 +331,16 @@ RT_DEV bool box_slab_t(const DShape<float>& s, const Ray<float>& ray, const RayI
   return enter_ok | leave_ok;
 }
 
+// Entry and exit distances of the line through a box (no range applied); false when the line misses it.
+RT_DEV bool box_slab_span(const DShape<float>& s, const Ray<float>& ray, const RayInv<float>& ri, float& tn, float& tf) {
+  const float x0 = (s.p[0] - ray.o.x) * ri.inv.x, x1 = (s.p[3] - ray.o.x) * ri.inv.x;
+  const float y0 = (s.p[1] - ray.o.y) * ri.inv.y, y1 = (s.p[4] - ray.o.y) * ri.inv.y;
+  const float z0 = (s.p[2] - ray.o.z) * ri.inv.z, z1 = (s.p[5] - ray.o.z) * ri.inv.z;
+  tn = rt_max(rt_max(rt_min(x0, x1), rt_min(y0, y1)), rt_min(z0, z1));
+  tf = rt_min(rt_min(rt_max(x0, x1), rt_max(y0, y1)), rt_max(z0, z1));
+  return tn <= tf;
+}
+
 // Single precision, scenes of a few leaves: every leaf is tested, in the order the tree would visit them, with the same
 // shrinking t_max; only the root box is kept as an early out.  A box test can only skip leaves the ray does not hit (up to
 // rounding at grazing incidence, which the single-precision tolerance covers), and with incoherent rays every wave visits
@@ -363,7 +373,38 @@ RT_DEV bool traverse_flat(const SceneView<float, C>& sv, int start, const Ray<fl
           bool medium = false;
           if constexpr (C::has(F_MEDIUM)) medium = (ob.flags & OBJ_MEDIUM) != 0u;
           if (medium) {
-            ok = leaf_t<float, C>(sv, word, ray, ri, t_min, closest, media, org, t, side);
+            if (s.tag == SH_BOX) {
+              // src/constant_medium.rs:41-111 with a box boundary: the first crossing of the whole line is where the ray enters
+              // the three slabs, the first one at least 0.0001 later is where it leaves them; one slab evaluation gives both.
+              Ray<float> moved;
+              to_local(ob, ray, moved, local);
+              if (ob.flags & OBJ_ROTATE_Y) {
+                rl.inv.x = __builtin_amdgcn_rcpf(local.d.x);
+                rl.inv.z = __builtin_amdgcn_rcpf(local.d.z);
+              }
+              float tn, tf;
+              const bool cross = box_slab_span(s, local, rl, tn, tf);
+              float t_after = tn + 0.0001f;
+              if (!(t_after > tn)) t_after = nextafterf(tn, Lim<float>::inf());
+              float t1 = tn, t2 = tf;
+              bool in = cross & (tf >= t_after);
+              if (t1 < t_min) t1 = t_min;
+              if (t2 > closest) t2 = closest;
+              in = in & !(t1 >= t2);
+              if (t1 < 0.0f) t1 = 0.0f;
+              if (in) {
+                const float ray_length = length(ray.d);
+                const float distance_inside_boundary = (t2 - t1) * ray_length;
+                const float hit_distance = ob.neg_inv_density * gen_log01(media, (uint32_t)s.obj_id, 0.0f);
+                if (!(hit_distance > distance_inside_boundary)) {
+                  t = t1 + hit_distance / ray_length;
+                  side = SIDE_MEDIUM;
+                  ok = true;
+                }
+              }
+            } else {
+              ok = leaf_t<float, C>(sv, word, ray, ri, t_min, closest, media, org, t, side);
+            }
           } else {
             Ray<float> moved;
             to_local(ob, ray, moved, local);
