@@ -107,7 +107,7 @@ RT_DEV bool sphere_roots(V3<double> center, const Ray<double>& ray, double radiu
 }
 // Single precision: `half_b^2 - a*c` cancels catastrophically for the radius-1000 ground spheres and for spheres far from
 // the ray origin, so oc, the three coefficients, the discriminant and the numerator -half_b -/+ sqrt(D) are formed in f64
-// from the f32 inputs (products of floats are exact in double); the square root and the division stay in f32.
+// from the f32 inputs (products of floats are exact in double); the square root and the division (a reciprocal) stay in f32.
 RT_DEV bool sphere_roots(V3<float> center, const Ray<float>& ray, float radius, float t_min, float t_max, float& root, bool on_surface) {
   double ocx = (double)ray.o.x - (double)center.x, ocy = (double)ray.o.y - (double)center.y, ocz = (double)ray.o.z - (double)center.z;
   double dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
@@ -117,14 +117,14 @@ RT_DEV bool sphere_roots(V3<float> center, const Ray<float>& ray, float radius, 
   if (on_surface) c = 0.0;  // the ray starts on this sphere: see Origin
   double discriminant = half_b * half_b - a * c;
   if (discriminant < 0.0) return false;
-  float sqrt_d = rt_sqrt((float)discriminant);
-  float af = (float)a;
-  root = (float)(-half_b - (double)sqrt_d) / af;
-  if (root < t_min || t_max < root) {
-    root = (float)(-half_b + (double)sqrt_d) / af;
-    if (root < t_min || t_max < root) return false;
-  }
-  return true;
+  const float sqrt_d = __builtin_amdgcn_sqrtf((float)discriminant);  // hardware square root and reciprocal, 1 ulp each
+  const float inv_a = __builtin_amdgcn_rcpf((float)a);
+  const float near = (float)(-half_b - (double)sqrt_d) * inv_a;
+  const float far = (float)(-half_b + (double)sqrt_d) * inv_a;
+  const bool near_ok = !(near < t_min) & !(t_max < near);
+  const bool far_ok = !(far < t_min) & !(t_max < far);
+  root = near_ok ? near : far;
+  return near_ok | far_ok;
 }
 
 // One axis-aligned rectangle.  AXIS is the constant axis; (A, B) the in-plane axes in the reference's (u, v) order.
