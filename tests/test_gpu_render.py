@@ -141,6 +141,30 @@ def test_cornell_matches_reference_sample_render(gpu, rtamd):
     assert np.abs(rgb.reshape(-1, 3).mean(0) - np.array(g["mean_8bit"])).max() < 2.0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", ["fused", "sorted", "persistent"])
+def test_ragged_and_empty_inputs(gpu, rtamd, oracle, pipeline):
+    """Frames smaller than a wavefront, sample ranges that are empty or do not start at 0, depth limits 0, 1 and 2."""
+    pl = {"fused": rtamd.PIPELINE_FUSED, "sorted": rtamd.PIPELINE_SORTED, "persistent": rtamd.PIPELINE_PERSISTENT}[pipeline]
+    for width, aspect in ((2, 1.0), (7, 7.0 / 3.0), (9, 1.0)):  # 2x2, 7x3, 9x9 pixels
+        hs, os_ = make_pair(rtamd, oracle, "cornell-box", width=width, aspect=aspect, spp=5)
+        gpu.upload(hs)
+        for s0, s1 in ((0, 5), (3, 5), (2, 2)):
+            want, cnt, _ = os_.render(s0, s1, seed=9)
+            _, got, st = gpu.render(s0, s1, precision=rtamd.F64, pipeline=pl, seed=9, want_rgb=s1 > s0)
+            assert st["rays"] == cnt["rays"] and st["camera_rays"] == hs.width * hs.height * (s1 - s0)
+            assert np.abs(got - want).max() <= 1e-9 * (1.0 + np.abs(want).max())
+    for depth in (1, 2):
+        hs, os_ = make_pair(rtamd, oracle, "simple-light", width=16, spp=3, depth=depth)
+        gpu.upload(hs)
+        want, cnt, _ = os_.render(0, 3, seed=2)
+        _, got, st = gpu.render(0, 3, precision=rtamd.F64, pipeline=pl, seed=2, depth=depth)
+        assert st["rays"] == cnt["rays"] and (depth > 1 or st["rays"] == hs.width * hs.height * 3)
+        assert np.abs(got - want).max() <= 1e-9 * (1.0 + np.abs(want).max())
+    _, got, st = gpu.render(0, 3, precision=rtamd.F64, pipeline=pl, seed=2, depth=0, want_rgb=False)  # ray_color(depth = 0) is black
+    assert st["rays"] == 0 and np.abs(got).max() == 0.0
+
+
 def test_error_paths(rtamd):
     """Every failure returns a code and a message; nothing falls back to a CPU path."""
     ctx = rtamd.Context(0)
