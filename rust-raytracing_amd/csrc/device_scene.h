@@ -126,9 +126,15 @@ constexpr uint32_t P_SPHERES = F_SPHERE | F_RECT | F_UV | F_CHECKER | F_NOISE | 
 using CfgBoxes = Cfg<P_BOXES, WALK_UNIFORM>;
 using CfgSmoke = Cfg<P_SMOKE, WALK_UNIFORM>;
 using CfgSpheres = Cfg<P_SPHERES, WALK_UNIFORM>;
+constexpr uint32_t P_BALLS = F_SPHERE | F_MOVING | F_CHECKER | F_METAL | F_DIELECTRIC | F_GRADIENT;  // random, mega-spheres
 using CfgAllLds = Cfg<F_ALL, WALK_LANE_LDS_ALL>;
 using CfgAllTop = Cfg<F_ALL, WALK_LANE_LDS_TOP>;
-enum { PRESET_BOXES = 0, PRESET_SMOKE = 1, PRESET_SPHERES = 2, PRESET_ALL_LDS = 3, PRESET_ALL_TOP = 4, PRESET_COUNT = 5 };
+using CfgBallsLds = Cfg<P_BALLS, WALK_LANE_LDS_ALL>;
+using CfgBallsTop = Cfg<P_BALLS, WALK_LANE_LDS_TOP>;
+enum {
+  PRESET_BOXES = 0, PRESET_SMOKE = 1, PRESET_SPHERES = 2, PRESET_ALL_LDS = 3, PRESET_ALL_TOP = 4, PRESET_BALLS_LDS = 5, PRESET_BALLS_TOP = 6,
+  PRESET_COUNT = 7
+};
 
 // Read-only record at a wave-uniform address in global memory that no kernel writes (the scene blob): loaded through
 // the constant address space, i.e. by scalar loads into scalar registers.
@@ -137,6 +143,21 @@ template <class T> RT_DEV T load_uniform(const T* p) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   typedef const __attribute__((address_space(4))) u32x4* const_ptr;
   const_ptr q = (const_ptr)(uintptr_t)p;
+  union {
+    T t;
+    u32x4 v[sizeof(T) / 16];
+  } u;
+#pragma unroll
+  for (unsigned k = 0; k < sizeof(T) / 16; ++k) u.v[k] = q[k];
+  return u.t;
+}
+
+// Record in the workgroup's LDS, read with LDS instructions whatever the optimiser knows about the pointer.
+template <class T> RT_DEV T load_lds(const T* p) {
+  static_assert(sizeof(T) % 16 == 0, "record size must be a multiple of 16 bytes");
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(3))) u32x4* lds_ptr;
+  lds_ptr q = (lds_ptr)(uintptr_t)(uint32_t)(uintptr_t)p;  // the low 32 bits of a generic LDS address are the LDS offset
   union {
     T t;
     u32x4 v[sizeof(T) / 16];
@@ -172,7 +193,9 @@ template <class R, class C> struct SceneView {
 
   RT_DEV DLink<R> link(int i) const {
     if constexpr (C::walk == WALK_LANE_LDS_TOP) {
-      if ((uint32_t)i < n_top) return top[i];
+      // the LDS copy is read through an LDS-typed pointer: a pointer that may be either LDS or global would turn every link
+      // fetch of the walk into a flat load
+      if ((uint32_t)i < n_top) return load_lds(top + i);
     }
     return links[i];
   }

@@ -318,20 +318,48 @@ RT_DEV bool leaf_hit(const SceneView<R, C>& sv, uint32_t leaf_word, const Ray<R>
 // BVHNode::hit (src/bvh.rs:108-119) over the threaded list, one traversal per lane.  The running `closest` is the
 // t_max every node of the reference's recursion would receive: it starts as the caller's t_max and becomes rec.t
 // after each accepted leaf, and nodes are visited in the reference's left-then-right order.
+// Box test of the per-lane walk.  Double: src/aabb.rs:30-46 as written.  Float: the slab distances come from one fused
+// multiply-add each (bound * 1/d - origin * 1/d, hardware reciprocal) and the interval logic from min/max, which agrees with the
+// reference's form except for rays lying exactly in a slab plane.
+template <class R> struct LaneBoxTest;
+template <> struct LaneBoxTest<double> {
+  V3<double> inv;
+  RT_DEV explicit LaneBoxTest(const Ray<double>& ray) : inv(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z) {}
+  RT_DEV bool hit(const DLink<double>& b, const Ray<double>& ray, double t_min, double t_max) const { return aabb_hit(b, ray, inv, t_min, t_max); }
+};
+template <> struct LaneBoxTest<float> {
+  V3<float> inv, oi;
+  RT_DEV explicit LaneBoxTest(const Ray<float>& ray)
+      : inv(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z)),
+        oi(ray.o.x * inv.x, ray.o.y * inv.y, ray.o.z * inv.z) {}
+  RT_DEV bool hit(const DLink<float>& b, const Ray<float>&, float t_min, float t_max) const {
+    const float x0 = b.bmin[0] * inv.x - oi.x, x1 = b.bmax[0] * inv.x - oi.x;
+    const float y0 = b.bmin[1] * inv.y - oi.y, y1 = b.bmax[1] * inv.y - oi.y;
+    const float z0 = b.bmin[2] * inv.z - oi.z, z1 = b.bmax[2] * inv.z - oi.z;
+    const float tn = rt_max(rt_max(rt_min(x0, x1), rt_min(y0, y1)), rt_max(rt_min(z0, z1), t_min));
+    const float tf = rt_min(rt_min(rt_max(x0, x1), rt_max(y0, y1)), rt_min(rt_max(z0, z1), t_max));
+    return tn < tf;
+  }
+};
+
 template <class R, class C, int LEVEL>
 RT_DEV bool traverse_lane(const SceneView<R, C>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
-  V3<R> inv_d((R)1 / ray.d.x, (R)1 / ray.d.y, (R)1 / ray.d.z);
+  const LaneBoxTest<R> box(ray);
   R closest = t_max;
   bool any = false;
   int i = start;
   while (i >= 0) {
-    const DLink<R> lk = sv.link(i);
-    if (lk.hit & LEAF_FLAG) {
-      if (leaf_hit<R, C, LEVEL>(sv, lk.hit, ray, t_min, closest, rec, media, org)) { closest = rec.t; any = true; }
-      i = lk.miss;
-    } else {
-      i = aabb_hit(lk, ray, inv_d, t_min, closest) ? (int)lk.hit : lk.miss;
+    DLink<R> lk = sv.link(i);
+    // Box entries first, until every lane of the wave stands on a leaf (or has left the tree): the leaf code below is then
+    // entered by the lanes together instead of once per lane that happens to reach a leaf.
+    while (!(lk.hit & LEAF_FLAG)) {
+      i = box.hit(lk, ray, t_min, closest) ? (int)lk.hit : lk.miss;
+      if (i < 0) break;
+      lk = sv.link(i);
     }
+    if (i < 0) break;
+    if (leaf_hit<R, C, LEVEL>(sv, lk.hit, ray, t_min, closest, rec, media, org)) { closest = rec.t; any = true; }
+    i = lk.miss;
   }
   return any;
 }

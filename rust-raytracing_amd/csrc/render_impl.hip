@@ -11,6 +11,8 @@ template <class R> KernelTable<R> table_for(int preset) {
     case PRESET_SMOKE: return kernel_table<R, PRESET_SMOKE>();
     case PRESET_SPHERES: return kernel_table<R, PRESET_SPHERES>();
     case PRESET_ALL_LDS: return kernel_table<R, PRESET_ALL_LDS>();
+    case PRESET_BALLS_LDS: return kernel_table<R, PRESET_BALLS_LDS>();
+    case PRESET_BALLS_TOP: return kernel_table<R, PRESET_BALLS_TOP>();
     default: return kernel_table<R, PRESET_ALL_TOP>();
   }
 }
@@ -110,6 +112,7 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
   HIP_TRY(hipMalloc((void**)&im.d_blob, blob.size()));
   HIP_TRY(hipMemcpy(im.d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
   if (preset == PRESET_ALL_LDS && lay.total_bytes > kLdsAllMax) preset = PRESET_ALL_TOP;  // the f64 image is larger than the f32 one
+  if (preset == PRESET_BALLS_LDS && lay.total_bytes > kLdsAllMax) preset = PRESET_BALLS_TOP;
   im.preset = preset;
   im.table = table_for<R>(preset);
   DeviceScene<R>& d = im.dev;
@@ -118,7 +121,7 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
   d.images = c->d_images;
   d.n_images = s.n_images;
   d.root_link = root_link;
-  d.lds_links = preset == PRESET_ALL_TOP ? std::min<uint32_t>(lay.n_links, kLdsTopMax / (uint32_t)sizeof(DLink<R>)) : 0u;
+  d.lds_links = (preset == PRESET_ALL_TOP || preset == PRESET_BALLS_TOP) ? std::min<uint32_t>(lay.n_links, kLdsTopMax / (uint32_t)sizeof(DLink<R>)) : 0u;
   im.lds_bytes = im.table.lds_bytes(lay, d.lds_links);
   auto v3 = [](const double* p) { return V3<R>((R)p[0], (R)p[1], (R)p[2]); };
   d.camera.origin = v3(s.camera.origin); d.camera.lower_left_corner = v3(s.camera.lower_left_corner);

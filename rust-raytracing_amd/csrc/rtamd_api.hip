@@ -242,7 +242,8 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   if (small && (feat & ~P_BOXES) == 0) preset = PRESET_BOXES;
   else if (small && (feat & ~P_SMOKE) == 0) preset = PRESET_SMOKE;
   else if (small && (feat & ~P_SPHERES) == 0) preset = PRESET_SPHERES;
-  const bool uniform = preset != PRESET_ALL_LDS;
+  else if ((feat & ~P_BALLS) == 0 && !(force && force[0] == '1')) preset = PRESET_BALLS_LDS;
+  const bool uniform = preset != PRESET_ALL_LDS && preset != PRESET_BALLS_LDS;
 
   std::vector<int> order;
   if (uniform) {

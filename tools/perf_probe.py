@@ -14,8 +14,11 @@ spass = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 width = int(sys.argv[5]) if len(sys.argv) > 5 else 1920
 pipe = int(os.environ.get("PROBE_PIPELINE", "0"))
 ctx = rtamd.Context(0)
-sc = rtamd.Scene(scene, width=width, aspect=16.0 / 9.0, spp=spp, earth_path=os.path.join(REPO, "rust-raytracing_amd/assets/earthmap.ppm"))
+sc = rtamd.Scene(scene, width=width, aspect=16.0 / 9.0, spp=spp, earth_path=os.path.join(REPO, "rust-raytracing_amd/assets/earthmap.ppm"),
+                 mega_grid=int(os.environ.get("PROBE_MEGA", "0")))
+t_up = time.time()
 ctx.upload(sc)
+print("scene: %d objects, %d nodes, upload %.2f s" % (len(sc.objects()), len(sc.nodes()), time.time() - t_up), flush=True)
 for rep in range(int(os.environ.get("PROBE_REPS", "3"))):
     t0 = time.time()
     st = ctx.render_accum(None, 0, spp, precision=prec, samples_per_pass=spass, pipeline=pipe)
