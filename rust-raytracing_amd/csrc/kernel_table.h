@@ -35,7 +35,10 @@ template <class R, class C> KernelTable<R> make_table() {
   };
   t.paths_persistent = [](uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, unsigned long long total_paths,
                           unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
-    hipLaunchKernelGGL((k_paths_persistent<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
+    if constexpr (C::walk == WALK_UNIFORM)
+      hipLaunchKernelGGL((k_paths_persistent<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
+    else
+      hipLaunchKernelGGL((k_paths_stepwise<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
   };
   t.resident_blocks_per_cu = [](int kernel, uint32_t lds) {
     int n = 0;
@@ -44,7 +47,10 @@ template <class R, class C> KernelTable<R> make_table() {
       case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_fused<R, C>, (int)kBlockThreads, lds); break;
       case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<R, C>, (int)kBlockThreads, lds); break;
       case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade<R, C>, (int)kBlockThreads, lds); break;
-      case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths_persistent<R, C>, (int)kBlockThreads, lds); break;
+      case 3:
+        if constexpr (C::walk == WALK_UNIFORM) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths_persistent<R, C>, (int)kBlockThreads, lds);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths_stepwise<R, C>, (int)kBlockThreads, lds);
+        break;
       default: break;
     }
     return e == hipSuccess ? n : -1;

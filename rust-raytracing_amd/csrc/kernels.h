@@ -235,26 +235,19 @@ __global__ __launch_bounds__(256) void k_bounce_fused(DeviceScene<R> sc, FramePa
 // (pixel, sample, bounce), so its result does not depend on which lane or iteration it ran in.
 constexpr uint32_t kPathGrab = 2048;
 
-template <class R, class C>
-__global__ __launch_bounds__(256) void k_paths_persistent(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
-                                                          unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
-  extern __shared__ __align__(16) uint8_t lds[];
-  const SceneView<R, C> sv = make_view<R, C>(sc, lds);
-  const uint32_t lane = threadIdx.x & 63u;
-  // wave-uniform: the unstarted paths this wave owns are `grab_left` consecutive ones starting at pixel grab_pixel of sample
-  // grab_sample (path index = sample * n_pixels + pixel, kept as the pair so that no lane ever divides)
-  uint32_t grab_left = 0, grab_pixel = 0, grab_sample = 0;
-  bool exhausted = false;  // wave-uniform: the cursor has passed total_paths
-  bool active = false;
-  uint32_t bounce = 0;
-  unsigned long long n_rays = 0;
-  PathState<R> st;
-  RT_STAMP_INIT();
-  for (;;) {
-    RT_STAMP(6);
+// Hands unstarted paths to lanes.  Wave-uniform state: the wave owns `left` consecutive paths starting at pixel `pixel` of
+// sample `sample` (path index = sample * n_pixels + pixel, kept as the pair so that no lane ever divides).
+template <class R> struct PathFeeder {
+  uint32_t left = 0, pixel = 0, sample = 0;
+  bool exhausted = false;  // the global cursor has passed total_paths
+
+  // Gives every lane with `!active` a new path while there are any; lanes that receive one become active with bounce = 0.
+  RT_DEV void refill(const DeviceScene<R>& sc, const FrameParams& fp, unsigned long long total_paths, unsigned long long* path_cursor,
+                     PathState<R>& st, uint32_t& bounce, bool& active) {
+    const uint32_t lane = threadIdx.x & 63u;
     unsigned long long dead = __ballot(!active);
     while (dead != 0ull && !exhausted) {
-      if (grab_left == 0u) {
+      if (left == 0u) {
         unsigned long long b = 0;
         if (lane == 0u) b = atomicAdd(path_cursor, (unsigned long long)kPathGrab);
         uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
@@ -262,29 +255,69 @@ __global__ __launch_bounds__(256) void k_paths_persistent(DeviceScene<R> sc, Fra
         b = ((unsigned long long)hi << 32) | lo;
         if (b >= total_paths) { exhausted = true; break; }
         const unsigned long long e = b + kPathGrab < total_paths ? b + kPathGrab : total_paths;
-        grab_left = (uint32_t)(e - b);
-        grab_sample = (uint32_t)(b / fp.n_pixels);
-        grab_pixel = (uint32_t)(b - (unsigned long long)grab_sample * fp.n_pixels);
+        left = (uint32_t)(e - b);
+        sample = (uint32_t)(b / fp.n_pixels);
+        pixel = (uint32_t)(b - (unsigned long long)sample * fp.n_pixels);
       }
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
       const uint32_t n_dead = (uint32_t)__popcll(dead);
-      uint32_t n_take = grab_left < n_dead ? grab_left : n_dead;
-      const uint32_t row_left = fp.n_pixels - grab_pixel;  // do not run past the end of a sample in one step
+      uint32_t n_take = left < n_dead ? left : n_dead;
+      const uint32_t row_left = fp.n_pixels - pixel;  // do not run past the end of a sample in one step
       n_take = n_take < row_left ? n_take : row_left;
       if (!active && rank < n_take) {
-        st.pixel = grab_pixel + rank;
-        st.sample = fp.sample_base + grab_sample;
+        st.pixel = pixel + rank;
+        st.sample = fp.sample_base + sample;
         st.ray = primary_ray<R>(sc.camera, fp.width, fp.height, st.pixel, st.sample, fp.seed);
         st.thr = V3<R>((R)1, (R)1, (R)1);
         st.org = Origin();
         bounce = 0;
         active = true;
       }
-      grab_left -= n_take;
-      grab_pixel += n_take;
-      if (grab_pixel == fp.n_pixels) { grab_pixel = 0u; grab_sample += 1u; }
+      left -= n_take;
+      pixel += n_take;
+      if (pixel == fp.n_pixels) { pixel = 0u; sample += 1u; }
       dead = __ballot(!active);
     }
+  }
+};
+
+// What ray_color does with the result of world.hit (src/render.rs:159-176): background on a miss, else emitted light and the
+// scattered ray.  Returns whether the path goes on; `bounce` counts the closest-hit queries made so far.
+template <class R, class C>
+RT_DEV bool continue_path(const SceneView<R, C>& sv, const DeviceScene<R>& sc, const FrameParams& fp, PathState<R>& st, uint32_t& bounce, bool hit,
+                          Rec<R>& rec, R* accum) {
+  if (!hit) {
+    add_radiance(accum, st.pixel, st.thr * background_color<R, C>(sc.background, st.ray.d));
+    return false;
+  }
+  Stream rng(fp.seed, st.pixel, st.sample, bounce, STAGE_SCATTER);
+  V3<R> emitted, attenuation;
+  Ray<R> scattered;
+  const bool alive = shade_hit<R, C>(sv, st.ray, rec, rng, emitted, attenuation, scattered);
+  add_radiance(accum, st.pixel, st.thr * emitted);
+  ++bounce;
+  if (!(alive && bounce < fp.max_depth)) return false;  // ray_color(depth == 0) contributes nothing (src/render.rs:151-153)
+  st.thr = st.thr * attenuation;
+  st.ray = scattered;
+  st.org = Origin(rec.leaf, rec.side);
+  return true;
+}
+
+template <class R, class C>
+__global__ __launch_bounds__(256) void k_paths_persistent(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
+                                                          unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const SceneView<R, C> sv = make_view<R, C>(sc, lds);
+  const uint32_t lane = threadIdx.x & 63u;
+  PathFeeder<R> feeder;
+  bool active = false;
+  uint32_t bounce = 0;
+  unsigned long long n_rays = 0;
+  PathState<R> st;
+  RT_STAMP_INIT();
+  for (;;) {
+    RT_STAMP(6);
+    feeder.refill(sc, fp, total_paths, path_cursor, st, bounce, active);
     RT_STAMP(0);
     const unsigned long long live = __ballot(active);
     if (live == 0ull) break;
@@ -297,29 +330,76 @@ __global__ __launch_bounds__(256) void k_paths_persistent(DeviceScene<R> sc, Fra
       hit = closest_hit<R, C>(sv, sc.root_link, st.ray, (R)0.001, Lim<R>::inf(), rec, media, st.org);
     }
     RT_STAMP(1);
-    if (active) {
-      if (!hit) {
-        add_radiance(accum, st.pixel, st.thr * background_color<R, C>(sc.background, st.ray.d));
-        active = false;
-      } else {
-        Stream rng(fp.seed, st.pixel, st.sample, bounce, STAGE_SCATTER);
-        V3<R> emitted, attenuation;
-        Ray<R> scattered;
-        const bool alive = shade_hit<R, C>(sv, st.ray, rec, rng, emitted, attenuation, scattered);
-        add_radiance(accum, st.pixel, st.thr * emitted);
-        ++bounce;
-        if (alive && bounce < fp.max_depth) {  // ray_color(depth == 0) contributes nothing (src/render.rs:151-153)
-          st.thr = st.thr * attenuation;
-          st.ray = scattered;
-          st.org = Origin(rec.leaf, rec.side);
-        } else {
-          active = false;
-        }
-      }
-    }
+    if (active) active = continue_path<R, C>(sv, sc, fp, st, bounce, hit, rec, accum);
     RT_STAMP(2);
   }
   RT_STAMP_FLUSH(ray_count);
+  if (lane == 0u && n_rays != 0ull) atomicAdd(ray_count, n_rays);
+}
+
+// The same pipeline for scenes whose tree every lane walks on its own.  Walks differ in length by an order of magnitude from ray
+// to ray, so waiting for the slowest lane of a wave before shading leaves most lanes idle.  Here the tree position is part of the
+// lane's state: every turn of the outer loop advances all walking lanes by a bounded number of entries, and as soon as
+// kRestartLanes lanes have finished their walk they are shaded, given their next ray (or a new path) and sent back into the tree,
+// while the other lanes keep their place.
+constexpr uint32_t kRestartLanes = 16;
+constexpr int kBoxStepsPerTurn = 6;
+constexpr int kTurnsPerCheck = 4;
+
+template <class R, class C>
+__global__ __launch_bounds__(256) void k_paths_stepwise(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
+                                                        unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const SceneView<R, C> sv = make_view<R, C>(sc, lds);
+  const uint32_t lane = threadIdx.x & 63u;
+  PathFeeder<R> feeder;
+  bool active = false;  // the lane holds a path
+  uint32_t bounce = 0;
+  unsigned long long n_rays = 0;
+  PathState<R> st;
+  // walk state of the lane's current ray
+  int i = LINK_END;     // entry to look at next; LINK_END = no walk in progress
+  DLink<R> lk{};        // entry i
+  R closest = Lim<R>::inf();
+  bool any = false;
+  Rec<R> rec;
+  LaneBoxTest<R> box(Ray<R>{});
+  for (;;) {
+    const unsigned long long idle = __ballot(i < 0);
+    if ((uint32_t)__popcll(idle) >= kRestartLanes || idle == ~0ull) {
+      if (i < 0 && active) active = continue_path<R, C>(sv, sc, fp, st, bounce, any, rec, accum);
+      feeder.refill(sc, fp, total_paths, path_cursor, st, bounce, active);
+      const bool start = i < 0 && active;
+      n_rays += (unsigned long long)__popcll(__ballot(start));
+      if (start) {
+        box = LaneBoxTest<R>(st.ray);
+        i = sc.root_link;
+        lk = sv.link(i);
+        closest = Lim<R>::inf();
+        any = false;
+        rec = Rec<R>();  // a fresh HitRecord per world.hit call (src/render.rs:157)
+      }
+      if (__ballot(i >= 0) == 0ull) break;  // no walk in progress and no path left to start
+    }
+#pragma unroll 1
+    for (int turn = 0; turn < kTurnsPerCheck; ++turn) {
+#pragma unroll 1
+      for (int k = 0; k < kBoxStepsPerTurn; ++k) {
+        const bool at_box = i >= 0 && !(lk.hit & LEAF_FLAG);
+        if (__ballot(at_box) == 0ull) break;
+        if (at_box) {
+          i = box.hit(lk, st.ray, (R)0.001, closest) ? (int)lk.hit : lk.miss;
+          if (i >= 0) lk = sv.link(i);
+        }
+      }
+      if (i >= 0 && (lk.hit & LEAF_FLAG)) {
+        Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
+        if (leaf_hit<R, C, 0>(sv, lk.hit, st.ray, (R)0.001, closest, rec, media, st.org)) { closest = rec.t; any = true; }
+        i = lk.miss;
+        if (i >= 0) lk = sv.link(i);
+      }
+    }
+  }
   if (lane == 0u && n_rays != 0ull) atomicAdd(ray_count, n_rays);
 }
 
