@@ -26,6 +26,10 @@ template <class R> struct KernelTable {
 
 constexpr uint32_t kBlockThreads = 256;
 
+// Per-lane walks use the stepwise kernel, except the presets that carry nested trees: their walk state does not fit the
+// register file at a useful occupancy, and the monolithic kernel is the faster of the two there.
+template <class C> constexpr bool use_stepwise() { return C::walk != WALK_UNIFORM && !C::has(F_NESTED); }
+
 template <class R, class C> KernelTable<R> make_table() {
   KernelTable<R> t;
   t.lds_bytes = [](const BlobLayout& lay, uint32_t lds_links) { return lds_bytes_for<R, C>(lay, lds_links); };
@@ -35,7 +39,7 @@ template <class R, class C> KernelTable<R> make_table() {
   };
   t.paths_persistent = [](uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, unsigned long long total_paths,
                           unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
-    if constexpr (C::walk == WALK_UNIFORM)
+    if constexpr (!use_stepwise<C>())
       hipLaunchKernelGGL((k_paths_persistent<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
     else
       hipLaunchKernelGGL((k_paths_stepwise<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
@@ -48,7 +52,7 @@ template <class R, class C> KernelTable<R> make_table() {
       case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<R, C>, (int)kBlockThreads, lds); break;
       case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade<R, C>, (int)kBlockThreads, lds); break;
       case 3:
-        if constexpr (C::walk == WALK_UNIFORM) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths_persistent<R, C>, (int)kBlockThreads, lds);
+        if constexpr (!use_stepwise<C>()) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths_persistent<R, C>, (int)kBlockThreads, lds);
         else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths_stepwise<R, C>, (int)kBlockThreads, lds);
         break;
       default: break;

@@ -342,9 +342,14 @@ __global__ __launch_bounds__(256) void k_paths_persistent(DeviceScene<R> sc, Fra
 // lane's state: every turn of the outer loop advances all walking lanes by a bounded number of entries, and as soon as
 // kRestartLanes lanes have finished their walk they are shaded, given their next ray (or a new path) and sent back into the tree,
 // while the other lanes keep their place.
-constexpr uint32_t kRestartLanes = 16;
-constexpr int kBoxStepsPerTurn = 6;
-constexpr int kTurnsPerCheck = 4;
+#ifndef RT_RESTART_LANES
+#define RT_RESTART_LANES 24
+#define RT_BOX_STEPS 4
+#define RT_TURNS 4
+#endif
+constexpr uint32_t kRestartLanes = RT_RESTART_LANES;
+constexpr int kBoxStepsPerTurn = RT_BOX_STEPS;
+constexpr int kTurnsPerCheck = RT_TURNS;
 
 template <class R, class C>
 __global__ __launch_bounds__(256) void k_paths_stepwise(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
