@@ -262,8 +262,10 @@ class Context:
         _check(self.L.rt_render_accum(self.h, C.byref(p), C.c_void_p(accum_dev_ptr) if accum_dev_ptr else None, C.byref(st)))
         return st.as_dict()
 
-    def resolve(self, accum_dev_ptr, width, height, spp, precision=F32):
-        rgb = np.zeros((height, width, 3), dtype=np.uint8)
+    def resolve(self, accum_dev_ptr, width, height, spp, precision=F32, out=None):
+        """rt_resolve; `out` (uint8 [height, width, 3], e.g. a view of pinned memory) is filled in place when given."""
+        rgb = out if out is not None else np.zeros((height, width, 3), dtype=np.uint8)
+        assert rgb.dtype == np.uint8 and rgb.shape == (height, width, 3) and rgb.flags["C_CONTIGUOUS"]
         _check(self.L.rt_resolve(self.h, C.c_void_p(accum_dev_ptr) if accum_dev_ptr else None, width, height, spp, precision, _p(rgb)))
         return rgb
 
