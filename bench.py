@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the bounded CPU sample")
     ap.add_argument("--save", default="", help="rank 0 writes the last image here (.png/.ppm)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo = rehearsal of the multi-rank path on a box with fewer GPUs than ranks (sums travel through host memory)")
     args = ap.parse_args()
 
     import numpy as np
@@ -63,6 +65,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path to time)")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -70,7 +74,10 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
 
     prec = rtamd.F64 if args.precision == "f64" else rtamd.F32
     pipe = {"auto": rtamd.PIPELINE_AUTO, "fused": rtamd.PIPELINE_FUSED, "sorted": rtamd.PIPELINE_SORTED,
@@ -90,8 +97,14 @@ def main():
         accum.zero_()
         torch.cuda.synchronize()  # the library renders on its own stream
         st = ctx.render_accum(accum.data_ptr(), s0, s1, precision=prec, pipeline=pipe, samples_per_pass=args.samples_per_pass)
-        if dist is not None:
+        if dist is not None and args.backend == "nccl":
             dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: W*H*4 values, once per frame
+            torch.cuda.synchronize()
+        elif dist is not None:
+            host = accum.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                accum.copy_(host)
             torch.cuda.synchronize()
         rgb = ctx.resolve(accum.data_ptr(), W, H, args.spp, precision=prec, out=rgb_host) if rank == 0 else None
         return st, rgb
@@ -117,10 +130,11 @@ def main():
     bounce_ms = float(sum(s["bounce_kernel_ms"] for s in stats))
     launches = float(sum(s["bounce_kernel_launches"] for s in stats))
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        red_dev = dev if args.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        r = torch.tensor([rays], dtype=torch.float64, device=dev)
+        r = torch.tensor([rays], dtype=torch.float64, device=red_dev)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         rays_all = float(r.item())
     else:
