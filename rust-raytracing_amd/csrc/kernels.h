@@ -234,6 +234,10 @@ __global__ __launch_bounds__(256) void k_bounce_fused(DeviceScene<R> sc, FramePa
 // queues: nothing is written to memory between bounces except the radiance sums.  A path's random streams are keyed by
 // (pixel, sample, bounce), so its result does not depend on which lane or iteration it ran in.
 constexpr uint32_t kPathGrab = 2048;
+#ifndef RT_NESTED_WAVES
+#define RT_NESTED_WAVES 4
+#endif
+
 
 // Hands unstarted paths to lanes.  Wave-uniform state: the wave owns `left` consecutive paths starting at pixel `pixel` of
 // sample `sample` (path index = sample * n_pixels + pixel, kept as the pair so that no lane ever divides).
@@ -303,8 +307,9 @@ RT_DEV bool continue_path(const SceneView<R, C>& sv, const DeviceScene<R>& sc, c
   return true;
 }
 
+// Presets with nested trees want 250 registers; asking for four waves per SIMD (128 registers, some spills) is the faster trade.
 template <class R, class C>
-__global__ __launch_bounds__(256) void k_paths_persistent(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
+__global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : 1) void k_paths_persistent(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
                                                           unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
   extern __shared__ __align__(16) uint8_t lds[];
   const SceneView<R, C> sv = make_view<R, C>(sc, lds);
