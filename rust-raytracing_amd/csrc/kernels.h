@@ -347,6 +347,9 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : 1) void k
 // lane's state: every turn of the outer loop advances all walking lanes by a bounded number of entries, and as soon as
 // kRestartLanes lanes have finished their walk they are shaded, given their next ray (or a new path) and sent back into the tree,
 // while the other lanes keep their place.
+#ifndef RT_STEP_WAVES
+#define RT_STEP_WAVES 1
+#endif
 #ifndef RT_RESTART_LANES
 #define RT_RESTART_LANES 24
 #define RT_BOX_STEPS 4
@@ -357,7 +360,7 @@ constexpr int kBoxStepsPerTurn = RT_BOX_STEPS;
 constexpr int kTurnsPerCheck = RT_TURNS;
 
 template <class R, class C>
-__global__ __launch_bounds__(256) void k_paths_stepwise(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
+__global__ __launch_bounds__(256, RT_STEP_WAVES) void k_paths_stepwise(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
                                                         unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
   extern __shared__ __align__(16) uint8_t lds[];
   const SceneView<R, C> sv = make_view<R, C>(sc, lds);
