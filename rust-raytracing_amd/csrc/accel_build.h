@@ -1,0 +1,303 @@
+// Host side: a tree of the library's own for the single-precision per-lane walk.
+//
+// The tree the caller hands over is the reference's (src/bvh.rs:19-76: a random axis per node, median split, boxes as the
+// reference computes them, the same object inserted many times where the scene does that).  The double-precision kernels walk
+// exactly that tree, because the order of its leaves decides ties and its boxes decide what a ray can reach.  The closest hit
+// itself does not depend on the tree: any hierarchy of conservative boxes over the same objects finds the same surface, except
+// that among exactly coincident surfaces another one may be reported.  The single-precision kernels (compared with the
+// reference by tolerance, not bit for bit) therefore walk a tree built here:
+//   * objects that are exact copies of one another (same wrapper, same shape, materials equal by value) are reduced to the copy
+//     the reference's walk would report, the last one it visits - the `random` scene inserts its three large spheres 22 times;
+//   * boxes are tight boxes of the shapes over the shutter interval (a negative radius does not invert them);
+//   * the split is chosen by the surface-area heuristic over 16 bins per axis.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <vector>
+
+#include "context.h"
+
+namespace rti {
+
+struct Box3d {
+  double mn[3], mx[3];
+  void reset() { for (int k = 0; k < 3; ++k) { mn[k] = std::numeric_limits<double>::infinity(); mx[k] = -mn[k]; } }
+  void grow(const Box3d& b) { for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], b.mn[k]); mx[k] = std::max(mx[k], b.mx[k]); } }
+  double area() const {
+    double d[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+    if (d[0] < 0 || d[1] < 0 || d[2] < 0) return 0.0;
+    return 2.0 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
+  }
+};
+
+class FastTreeBuilder {
+ public:
+  explicit FastTreeBuilder(const rt_scene_desc& s) : s_(s) {}
+
+  // `ref` are the links of the reference trees before reordering, `ref_root` / `ref_sub_root` their roots.
+  // Fills `links` (top-level tree first, then the nested ones), `root` and `sub_root`.
+  void build(const std::vector<TmpLink>& ref, int ref_root, const std::vector<int>& ref_sub_root, std::vector<TmpLink>& links, int& root,
+             std::vector<int>& sub_root) {
+    links.clear();
+    sub_root.assign((size_t)s_.n_objects, LINK_END);
+    nested_box_.assign((size_t)s_.n_objects, Box3d{});
+    // nested trees first: their root boxes are the geometry boxes of the objects that hold them
+    std::vector<std::vector<TmpLink>> nested_links;
+    std::vector<int> nested_owner;
+    for (int o = 0; o < s_.n_objects; ++o) {
+      if (!(s_.objects[o].flags & RT_OBJ_SUB_BVH)) continue;
+      std::vector<int> objs = leaves_in_visiting_order(ref, ref_sub_root[(size_t)o], s_.n_objects);
+      nested_links.emplace_back();
+      nested_owner.push_back(o);
+      Box3d rb;
+      emit_tree(objs, (int)nested_links.size(), nested_links.back(), rb);
+      nested_box_[(size_t)o] = rb;
+    }
+    std::vector<int> top = leaves_in_visiting_order(ref, ref_root, s_.n_objects);
+    Box3d unused;
+    emit_tree(top, 0, links, unused);
+    root = 0;
+    for (size_t k = 0; k < nested_links.size(); ++k) {
+      const int base = (int)links.size();
+      for (TmpLink l : nested_links[k]) {
+        if (!(l.hit & LEAF_FLAG)) l.hit += (uint32_t)base;
+        if (l.miss >= 0) l.miss += base;
+        links.push_back(l);
+      }
+      sub_root[(size_t)nested_owner[k]] = base;
+    }
+  }
+
+ private:
+  const rt_scene_desc& s_;
+  std::vector<Box3d> nested_box_;
+  struct Node {
+    Box3d box;
+    int left = -1, right = -1, obj = -1;
+  };
+
+  // Objects of one reference tree, each once, ordered by the LAST time the reference's walk visits them.
+  static std::vector<int> leaves_in_visiting_order(const std::vector<TmpLink>& ref, int start, int n_objects) {
+    std::vector<int> seq;
+    for (int i = start; i >= 0;) {
+      const TmpLink& l = ref[(size_t)i];
+      if (l.hit & LEAF_FLAG) { seq.push_back((int)(l.hit & LEAF_INDEX_MASK)); i = l.miss; }
+      else i = (int)l.hit;
+    }
+    std::vector<int> out;
+    std::vector<char> seen((size_t)n_objects, 0);
+    for (size_t k = seq.size(); k-- > 0;)
+      if (!seen[(size_t)seq[k]]) { seen[(size_t)seq[k]] = 1; out.push_back(seq[k]); }
+    std::reverse(out.begin(), out.end());
+    return out;
+  }
+
+  // Everything that decides what a ray sees of an object, by value.
+  std::vector<double> signature(int o) const {
+    const rt_object& ob = s_.objects[o];
+    std::vector<double> v;
+    v.push_back((double)ob.flags);
+    for (int k = 0; k < 3; ++k) v.push_back(ob.offset[k]);
+    v.push_back(ob.sin_theta); v.push_back(ob.cos_theta);
+    const rt_shape& sh = s_.shapes[ob.geom];
+    v.push_back((double)sh.tag);
+    for (int k = 0; k < 9; ++k) v.push_back(sh.p[k]);
+    const rt_material& m = s_.materials[sh.material];
+    v.push_back((double)m.tag);
+    for (int k = 0; k < 3; ++k) v.push_back(m.albedo[k]);
+    v.push_back(m.fuzz); v.push_back(m.ir);
+    if (m.texture >= 0 && m.texture < s_.n_textures) {
+      const rt_texture& t = s_.textures[m.texture];
+      v.push_back((double)t.tag);
+      if (t.tag == RT_TEX_SOLID) for (int k = 0; k < 3; ++k) v.push_back(t.color[k]);
+      else v.push_back((double)m.texture);  // other textures: the same record only
+    } else {
+      v.push_back(-1.0);
+    }
+    return v;
+  }
+
+  static Box3d sphere_box(const double c[3], double r) {
+    r = std::fabs(r);
+    Box3d b;
+    for (int k = 0; k < 3; ++k) { b.mn[k] = c[k] - r; b.mx[k] = c[k] + r; }
+    return b;
+  }
+  Box3d shape_box(const rt_shape& sh) const {
+    const double pad = 1e-4;
+    Box3d b;
+    switch (sh.tag) {
+      case RT_SHAPE_SPHERE: return sphere_box(sh.p, sh.p[3]);
+      case RT_SHAPE_MOVING_SPHERE: {  // centre0 p[0..2], centre1 p[3..5], radius p[6], time0 p[7], time1 p[8]; rays have time in [0, 1)
+        b.reset();
+        for (double time : {0.0, 1.0}) {
+          double f = (time - sh.p[7]) / (sh.p[8] - sh.p[7]);
+          double c[3] = {sh.p[0] + f * (sh.p[3] - sh.p[0]), sh.p[1] + f * (sh.p[4] - sh.p[1]), sh.p[2] + f * (sh.p[5] - sh.p[2])};
+          b.grow(sphere_box(c, sh.p[6]));
+        }
+        return b;
+      }
+      case RT_SHAPE_RECT_XY: b = Box3d{{sh.p[0], sh.p[2], sh.p[4] - pad}, {sh.p[1], sh.p[3], sh.p[4] + pad}}; return b;
+      case RT_SHAPE_RECT_XZ: b = Box3d{{sh.p[0], sh.p[4] - pad, sh.p[2]}, {sh.p[1], sh.p[4] + pad, sh.p[3]}}; return b;
+      case RT_SHAPE_RECT_YZ: b = Box3d{{sh.p[4] - pad, sh.p[0], sh.p[2]}, {sh.p[4] + pad, sh.p[1], sh.p[3]}}; return b;
+      default: b = Box3d{{sh.p[0], sh.p[1], sh.p[2]}, {sh.p[3], sh.p[4], sh.p[5]}}; return b;
+    }
+  }
+  Box3d object_box(int o) const {
+    const rt_object& ob = s_.objects[o];
+    Box3d g = (ob.flags & RT_OBJ_SUB_BVH) ? nested_box_[(size_t)o] : shape_box(s_.shapes[ob.geom]);
+    if (ob.flags & RT_OBJ_ROTATE_Y) {  // world x = cos * x + sin * z, world z = -sin * x + cos * z (src/hittable.rs:229-232)
+      Box3d r;
+      r.reset();
+      for (int i = 0; i < 8; ++i) {
+        double x = (i & 1) ? g.mx[0] : g.mn[0], y = (i & 2) ? g.mx[1] : g.mn[1], z = (i & 4) ? g.mx[2] : g.mn[2];
+        double c[3] = {ob.cos_theta * x + ob.sin_theta * z, y, -ob.sin_theta * x + ob.cos_theta * z};
+        Box3d p{{c[0], c[1], c[2]}, {c[0], c[1], c[2]}};
+        r.grow(p);
+      }
+      g = r;
+    }
+    if (ob.flags & RT_OBJ_TRANSLATE)
+      for (int k = 0; k < 3; ++k) { g.mn[k] += ob.offset[k]; g.mx[k] += ob.offset[k]; }
+    const double eps = 1e-6;  // the single-precision box test rounds: keep a margin of a few ulps at scene scale
+    for (int k = 0; k < 3; ++k) {
+      double m = eps * std::max({1.0, std::fabs(g.mn[k]), std::fabs(g.mx[k])});
+      g.mn[k] -= m; g.mx[k] += m;
+    }
+    return g;
+  }
+
+  int build_node(std::vector<Node>& nodes, std::vector<int>& ids, const std::vector<Box3d>& boxes, int lo, int hi) {
+    const int me = (int)nodes.size();
+    nodes.push_back(Node{});
+    Box3d bb, cb;
+    bb.reset(); cb.reset();
+    for (int k = lo; k < hi; ++k) {
+      const Box3d& b = boxes[(size_t)ids[(size_t)k]];
+      bb.grow(b);
+      Box3d c;
+      for (int a = 0; a < 3; ++a) c.mn[a] = c.mx[a] = 0.5 * (b.mn[a] + b.mx[a]);
+      cb.grow(c);
+    }
+    nodes[(size_t)me].box = bb;
+    if (hi - lo == 1) { nodes[(size_t)me].obj = ids[(size_t)lo]; return me; }
+    constexpr int kBins = 16;
+    double best_cost = std::numeric_limits<double>::infinity();
+    int best_axis = -1, best_split = -1;
+    for (int axis = 0; axis < 3; ++axis) {
+      const double ext = cb.mx[axis] - cb.mn[axis];
+      if (!(ext > 0.0)) continue;
+      Box3d bin_box[kBins];
+      int bin_n[kBins] = {0};
+      for (auto& b : bin_box) b.reset();
+      const double scale = kBins / ext;
+      for (int k = lo; k < hi; ++k) {
+        const Box3d& b = boxes[(size_t)ids[(size_t)k]];
+        int bi = std::min(kBins - 1, std::max(0, (int)((0.5 * (b.mn[axis] + b.mx[axis]) - cb.mn[axis]) * scale)));
+        bin_box[bi].grow(b);
+        bin_n[bi]++;
+      }
+      double right_area[kBins];
+      int right_n[kBins];
+      Box3d acc;
+      acc.reset();
+      int n = 0;
+      for (int b = kBins - 1; b > 0; --b) { acc.grow(bin_box[b]); n += bin_n[b]; right_area[b] = acc.area(); right_n[b] = n; }
+      acc.reset();
+      n = 0;
+      for (int b = 0; b + 1 < kBins; ++b) {
+        acc.grow(bin_box[b]);
+        n += bin_n[b];
+        if (n == 0 || right_n[b + 1] == 0) continue;
+        double cost = acc.area() * n + right_area[b + 1] * right_n[b + 1];
+        if (cost < best_cost) { best_cost = cost; best_axis = axis; best_split = b; }
+      }
+    }
+    int mid;
+    if (best_axis < 0) {
+      mid = (lo + hi) / 2;  // all centroids coincide
+    } else {
+      const double ext = cb.mx[best_axis] - cb.mn[best_axis];
+      const double scale = kBins / ext;
+      auto it = std::partition(ids.begin() + lo, ids.begin() + hi, [&](int id) {
+        const Box3d& b = boxes[(size_t)id];
+        int bi = std::min(kBins - 1, std::max(0, (int)((0.5 * (b.mn[best_axis] + b.mx[best_axis]) - cb.mn[best_axis]) * scale)));
+        return bi <= best_split;
+      });
+      mid = (int)(it - ids.begin());
+      if (mid == lo || mid == hi) mid = (lo + hi) / 2;
+    }
+    const int l = build_node(nodes, ids, boxes, lo, mid);
+    const int r = build_node(nodes, ids, boxes, mid, hi);
+    nodes[(size_t)me].left = l;
+    nodes[(size_t)me].right = r;
+    return me;
+  }
+
+  // Emits the subtree of `n` in visiting order; returns the index of its first link.
+  int emit(const std::vector<Node>& nodes, int n, int next, int depth, int tree, std::vector<TmpLink>& out) const {
+    const Node& nd = nodes[(size_t)n];
+    TmpLink l{};
+    l.depth = depth; l.tree = tree; l.miss = next;
+    const int me = (int)out.size();
+    if (nd.obj >= 0) {
+      l.hit = LEAF_FLAG | (s_.objects[nd.obj].flags == 0u ? LEAF_SIMPLE : 0u) | (uint32_t)nd.obj;
+      out.push_back(l);
+      return me;
+    }
+    for (int k = 0; k < 3; ++k) { l.bmin[k] = nd.box.mn[k]; l.bmax[k] = nd.box.mx[k]; }
+    out.push_back(l);
+    // children in visiting order right behind their parent: left subtree, then right subtree
+    const int left_first = me + 1;
+    // the right subtree's first index is only known after the left one has been emitted: emit left with a placeholder, patch after
+    const size_t before = out.size();
+    (void)emit(nodes, nd.left, -2, depth + 1, tree, out);
+    const int right_first = (int)out.size();
+    (void)emit(nodes, nd.right, next, depth + 1, tree, out);
+    for (size_t k = before; k < (size_t)right_first; ++k)
+      if (out[k].miss == -2) out[k].miss = right_first;
+    out[(size_t)me].hit = (uint32_t)left_first;
+    return me;
+  }
+
+  void emit_tree(const std::vector<int>& objs_in_order, int tree, std::vector<TmpLink>& out, Box3d& root_box) {
+    // copies: keep the last visited one
+    std::map<std::vector<double>, int> last;
+    std::vector<int> keep;
+    for (int o : objs_in_order) {
+      const rt_object& ob = s_.objects[o];
+      if (ob.flags & (RT_OBJ_MEDIUM | RT_OBJ_SUB_BVH)) { keep.push_back(o); continue; }
+      last[signature(o)] = o;
+    }
+    for (int o : objs_in_order) {
+      const rt_object& ob = s_.objects[o];
+      if (ob.flags & (RT_OBJ_MEDIUM | RT_OBJ_SUB_BVH)) continue;
+      if (last[signature(o)] == o) keep.push_back(o);
+    }
+    std::vector<Box3d> boxes((size_t)s_.n_objects);
+    for (int o : keep) boxes[(size_t)o] = object_box(o);
+    std::vector<Node> nodes;
+    nodes.reserve(keep.size() * 2);
+    (void)build_node(nodes, keep, boxes, 0, (int)keep.size());
+    root_box = nodes[0].box;
+    out.clear();
+    if (nodes[0].obj >= 0) {
+      // a single object: give it a box entry so that the walk starts on a box, as every other tree does
+      TmpLink b{};
+      for (int k = 0; k < 3; ++k) { b.bmin[k] = nodes[0].box.mn[k]; b.bmax[k] = nodes[0].box.mx[k]; }
+      b.hit = 1u; b.miss = LINK_END; b.depth = 0; b.tree = tree;
+      out.push_back(b);
+      TmpLink l{};
+      l.hit = LEAF_FLAG | (s_.objects[nodes[0].obj].flags == 0u ? LEAF_SIMPLE : 0u) | (uint32_t)nodes[0].obj;
+      l.miss = LINK_END; l.depth = 1; l.tree = tree;
+      out.push_back(l);
+      return;
+    }
+    (void)emit(nodes, 0, LINK_END, 0, tree, out);
+  }
+};
+
+}  // namespace rti

@@ -117,10 +117,17 @@ RT_DEV bool sphere_roots(V3<float> center, const Ray<float>& ray, float radius, 
   if (on_surface) c = 0.0;  // the ray starts on this sphere: see Origin
   double discriminant = half_b * half_b - a * c;
   if (discriminant < 0.0) return false;
-  const float sqrt_d = __builtin_amdgcn_sqrtf((float)discriminant);  // hardware square root and reciprocal, 1 ulp each
-  const float inv_a = __builtin_amdgcn_rcpf((float)a);
-  const float near = (float)(-half_b - (double)sqrt_d) * inv_a;
-  const float far = (float)(-half_b + (double)sqrt_d) * inv_a;
+  const float inv_a = __builtin_amdgcn_rcpf((float)a);  // hardware reciprocal, 1 ulp
+  if (on_surface) {
+    // c = 0: the roots are 0 (the surface the ray stands on: never a hit) and -2 half_b / a, formed without a square root so
+    // that no rounding of it can push the zero root past t_min (on a sphere of radius 1e5 it would)
+    root = (float)(-2.0 * half_b) * inv_a;
+    return !(root < t_min) & !(t_max < root);
+  }
+  // the square root in single precision, except for spheres so large that its rounding would be visible in t
+  const double sqrt_d = radius * radius > 1.0e4f ? __builtin_sqrt(discriminant) : (double)__builtin_amdgcn_sqrtf((float)discriminant);
+  const float near = (float)(-half_b - sqrt_d) * inv_a;
+  const float far = (float)(-half_b + sqrt_d) * inv_a;
   const bool near_ok = !(near < t_min) & !(t_max < near);
   const bool far_ok = !(far < t_min) & !(t_max < far);
   root = near_ok ? near : far;
@@ -318,9 +325,10 @@ RT_DEV bool leaf_hit(const SceneView<R, C>& sv, uint32_t leaf_word, const Ray<R>
 // BVHNode::hit (src/bvh.rs:108-119) over the threaded list, one traversal per lane.  The running `closest` is the
 // t_max every node of the reference's recursion would receive: it starts as the caller's t_max and becomes rec.t
 // after each accepted leaf, and nodes are visited in the reference's left-then-right order.
-// Box test of the per-lane walk.  Double: src/aabb.rs:30-46 as written.  Float: the slab distances come from one fused
-// multiply-add each (bound * 1/d - origin * 1/d, hardware reciprocal) and the interval logic from min/max, which agrees with the
-// reference's form except for rays lying exactly in a slab plane.
+// Box test of the per-lane walk.  Double: src/aabb.rs:30-46 as written.  Float: hardware reciprocals, slab distances as
+// (bound - origin) * 1/d (the difference first: folding the origin into a multiply-add loses the distance to rounding as soon as
+// the origin is far from zero compared with the box), interval logic by min/max, which agrees with the reference's form except
+// for rays lying exactly in a slab plane.
 template <class R> struct LaneBoxTest;
 template <> struct LaneBoxTest<double> {
   V3<double> inv;
@@ -328,14 +336,13 @@ template <> struct LaneBoxTest<double> {
   RT_DEV bool hit(const DLink<double>& b, const Ray<double>& ray, double t_min, double t_max) const { return aabb_hit(b, ray, inv, t_min, t_max); }
 };
 template <> struct LaneBoxTest<float> {
-  V3<float> inv, oi;
+  V3<float> inv;
   RT_DEV explicit LaneBoxTest(const Ray<float>& ray)
-      : inv(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z)),
-        oi(ray.o.x * inv.x, ray.o.y * inv.y, ray.o.z * inv.z) {}
-  RT_DEV bool hit(const DLink<float>& b, const Ray<float>&, float t_min, float t_max) const {
-    const float x0 = b.bmin[0] * inv.x - oi.x, x1 = b.bmax[0] * inv.x - oi.x;
-    const float y0 = b.bmin[1] * inv.y - oi.y, y1 = b.bmax[1] * inv.y - oi.y;
-    const float z0 = b.bmin[2] * inv.z - oi.z, z1 = b.bmax[2] * inv.z - oi.z;
+      : inv(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z)) {}
+  RT_DEV bool hit(const DLink<float>& b, const Ray<float>& ray, float t_min, float t_max) const {
+    const float x0 = (b.bmin[0] - ray.o.x) * inv.x, x1 = (b.bmax[0] - ray.o.x) * inv.x;
+    const float y0 = (b.bmin[1] - ray.o.y) * inv.y, y1 = (b.bmax[1] - ray.o.y) * inv.y;
+    const float z0 = (b.bmin[2] - ray.o.z) * inv.z, z1 = (b.bmax[2] - ray.o.z) * inv.z;
     const float tn = rt_max(rt_max(rt_min(x0, x1), rt_min(y0, y1)), rt_max(rt_min(z0, z1), t_min));
     const float tf = rt_min(rt_min(rt_max(x0, x1), rt_max(y0, y1)), rt_min(rt_max(z0, z1), t_max));
     return tn < tf;

@@ -2,6 +2,7 @@
 // per-precision render code.  No kernels in this file.
 #include <cstdlib>
 
+#include "accel_build.h"
 #include "context.h"
 
 namespace rti {
@@ -245,34 +246,51 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   else if ((feat & ~P_BALLS) == 0 && !(force && force[0] == '1')) preset = PRESET_BALLS_LDS;
   const bool uniform = preset != PRESET_ALL_LDS && preset != PRESET_BALLS_LDS;
 
-  std::vector<int> order;
-  if (uniform) {
-    // visiting order: follow the hit link of every box and the miss link of every leaf
-    for (int i = root; i >= 0; i = (lb.links[i].hit & LEAF_FLAG) ? lb.links[i].miss : (int)lb.links[i].hit) order.push_back(i);
-    if (order.size() != lb.links.size()) return fail(RT_E_INVALID, "rt_upload_scene: internal error while ordering links");
-  } else {
-    // sort by (nested?, depth): the first entries are the top levels of the main tree
-    order.resize(lb.links.size());
-    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-      const TmpLink &x = lb.links[a], &y = lb.links[b];
-      int kx = x.tree != 0, ky = y.tree != 0;
-      if (kx != ky) return kx < ky;
-      return x.depth < y.depth;
-    });
+  // Storage order of the links.  Small scenes: visiting order (the wave-uniform walk steps through it).  Otherwise by
+  // (nested?, depth): the first entries are the top levels of the main tree, which is what gets staged in LDS.
+  std::string order_err;
+  auto reorder = [&](const std::vector<TmpLink>& in, int& root_io, std::vector<int>& sub_root_io) {
+    std::vector<int> order;
+    if (uniform) {
+      for (int i = root_io; i >= 0; i = (in[i].hit & LEAF_FLAG) ? in[i].miss : (int)in[i].hit) order.push_back(i);
+      if (order.size() != in.size()) order_err = "rt_upload_scene: internal error while ordering links";
+    }
+    if (!uniform || !order_err.empty()) {
+      order.resize(in.size());
+      for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        const TmpLink &x = in[a], &y = in[b];
+        int kx = x.tree != 0, ky = y.tree != 0;
+        if (kx != ky) return kx < ky;
+        return x.depth < y.depth;
+      });
+    }
+    std::vector<int> new_index(order.size());
+    for (size_t i = 0; i < order.size(); ++i) new_index[order[i]] = (int)i;
+    std::vector<TmpLink> out(order.size());
+    for (size_t i = 0; i < order.size(); ++i) {
+      TmpLink l = in[order[i]];
+      if (!(l.hit & LEAF_FLAG)) l.hit = (uint32_t)new_index[l.hit];
+      if (l.miss >= 0) l.miss = new_index[l.miss];
+      out[i] = l;
+    }
+    root_io = new_index[root_io];
+    for (int& r : sub_root_io)
+      if (r >= 0) r = new_index[r];
+    return out;
+  };
+  // The single-precision per-lane walk gets a tree of the library's own (see accel_build.h) unless RTAMD_REFERENCE_TREE is set.
+  std::vector<TmpLink> fast_links;
+  int fast_root = LINK_END;
+  std::vector<int> fast_sub_root;
+  const bool own_tree = !uniform && !std::getenv("RTAMD_REFERENCE_TREE");
+  if (own_tree) {
+    FastTreeBuilder ftb(*s);
+    ftb.build(lb.links, root, sub_root, fast_links, fast_root, fast_sub_root);
+    fast_links = reorder(fast_links, fast_root, fast_sub_root);
   }
-  std::vector<int> new_index(order.size());
-  for (size_t i = 0; i < order.size(); ++i) new_index[order[i]] = (int)i;
-  std::vector<TmpLink> links(order.size());
-  for (size_t i = 0; i < order.size(); ++i) {
-    TmpLink l = lb.links[order[i]];
-    if (!(l.hit & LEAF_FLAG)) l.hit = (uint32_t)new_index[l.hit];
-    if (l.miss >= 0) l.miss = new_index[l.miss];
-    links[i] = l;
-  }
-  root = new_index[root];
-  for (int& r : sub_root)
-    if (r >= 0) r = new_index[r];
+  std::vector<TmpLink> links = reorder(lb.links, root, sub_root);
+  if (!order_err.empty()) return fail(RT_E_INVALID, order_err);
 
   // images
   if (s->n_images > 0) {
@@ -288,7 +306,8 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     HIP_TRY(hipMalloc((void**)&c->d_images, sizeof(DImage) * host_images.size()));
     HIP_TRY(hipMemcpy(c->d_images, host_images.data(), sizeof(DImage) * host_images.size(), hipMemcpyHostToDevice));
   }
-  rc = build_image<float>(c, *s, links, root, sub_root, preset, c->sf);
+  rc = own_tree ? build_image<float>(c, *s, fast_links, fast_root, fast_sub_root, preset, c->sf)
+                : build_image<float>(c, *s, links, root, sub_root, preset, c->sf);
   if (rc == RT_OK) rc = build_image<double>(c, *s, links, root, sub_root, preset, c->sd);
   if (rc != RT_OK) { free_scene(c); return rc; }
   c->has_scene = true;

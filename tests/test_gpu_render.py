@@ -80,6 +80,22 @@ def test_frame_f32_within_tolerance(gpu, rtamd, oracle, earth_rgb, name):
     assert abs(st["rays"] - cnt["rays"]) / cnt["rays"] < 5e-3
 
 
+def test_synthetic_sphere_field(gpu, rtamd, oracle):
+    """The synthetic large-scene generator at a small grid (1600 spheres, most of them moving, on a ground sphere of radius 1e5):
+    f64 against the oracle, f32 (which walks a tree of the library's own) against f64 by tolerance."""
+    hs, os_ = make_pair(rtamd, oracle, "mega-spheres", width=160, spp=4, mega_grid=20)
+    gpu.upload(hs)
+    want, cnt, _ = os_.render(0, 4, seed=13)
+    _, got, st = gpu.render(0, 4, precision=rtamd.F64, seed=13)
+    assert abs(int(st["rays"]) - int(cnt["rays"])) <= 1e-3 * cnt["rays"]
+    err = np.abs(got - want) / (np.abs(want) + 1e-3)
+    assert (err.reshape(-1, 3).max(axis=1) > 1e-9).mean() <= 1e-3
+    _, got32, st32 = gpu.render(0, 4, precision=rtamd.F32, seed=13)
+    assert abs(int(st32["rays"]) - int(cnt["rays"])) <= 5e-3 * cnt["rays"], (st32["rays"], cnt["rays"])
+    m32, m64 = np.clip(got32 / 4, 0, 1).reshape(-1, 3).mean(0), np.clip(want / 4, 0, 1).reshape(-1, 3).mean(0)
+    assert (np.abs(m32 - m64) / m64).max() < 1e-2, (m32, m64)
+
+
 def test_sample_ranges_add_up(gpu, rtamd):
     """Rendering [0,8) equals rendering [0,3) + [3,8): the stream is keyed by the global sample index (sample sharding)."""
     hs = rtamd.Scene("cornell-box", width=96, spp=8)
