@@ -28,7 +28,10 @@ constexpr uint32_t kBlockThreads = 256;
 
 // Per-lane walks use the stepwise kernel, except the presets that carry nested trees: their walk state does not fit the
 // register file at a useful occupancy, and the monolithic kernel is the faster of the two there.
-template <class C> constexpr bool use_stepwise() { return C::walk != WALK_UNIFORM && !C::has(F_NESTED); }
+#ifndef RT_STEPWISE_NESTED
+#define RT_STEPWISE_NESTED 0
+#endif
+template <class C> constexpr bool use_stepwise() { return C::walk != WALK_UNIFORM && (RT_STEPWISE_NESTED || !C::has(F_NESTED)); }
 
 template <class R, class C> KernelTable<R> make_table() {
   KernelTable<R> t;
