@@ -237,6 +237,10 @@ class FastTreeBuilder {
     return me;
   }
 
+  uint32_t leaf_word(int obj) const {
+    const uint32_t f = s_.objects[obj].flags;
+    return LEAF_FLAG | (f == 0u ? LEAF_SIMPLE : 0u) | ((f & RT_OBJ_SUB_BVH) ? LEAF_NESTED : 0u) | (uint32_t)obj;
+  }
   // Emits the subtree of `n` in visiting order; returns the index of its first link.
   int emit(const std::vector<Node>& nodes, int n, int next, int depth, int tree, std::vector<TmpLink>& out) const {
     const Node& nd = nodes[(size_t)n];
@@ -244,7 +248,7 @@ class FastTreeBuilder {
     l.depth = depth; l.tree = tree; l.miss = next;
     const int me = (int)out.size();
     if (nd.obj >= 0) {
-      l.hit = LEAF_FLAG | (s_.objects[nd.obj].flags == 0u ? LEAF_SIMPLE : 0u) | (uint32_t)nd.obj;
+      l.hit = leaf_word(nd.obj);
       out.push_back(l);
       return me;
     }
@@ -291,7 +295,7 @@ class FastTreeBuilder {
       b.hit = 1u; b.miss = LINK_END; b.depth = 0; b.tree = tree;
       out.push_back(b);
       TmpLink l{};
-      l.hit = LEAF_FLAG | (s_.objects[nodes[0].obj].flags == 0u ? LEAF_SIMPLE : 0u) | (uint32_t)nodes[0].obj;
+      l.hit = leaf_word(nodes[0].obj);
       l.miss = LINK_END; l.depth = 1; l.tree = tree;
       out.push_back(l);
       return;

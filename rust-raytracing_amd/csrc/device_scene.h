@@ -16,7 +16,8 @@ namespace rtd {
 constexpr int LINK_END = -1;
 constexpr uint32_t LEAF_FLAG = 0x80000000u;    // hit word of a leaf entry
 constexpr uint32_t LEAF_SIMPLE = 0x40000000u;  // object has no transform / medium / nested tree: test the shape directly
-constexpr uint32_t LEAF_INDEX_MASK = 0x3FFFFFFFu;
+constexpr uint32_t LEAF_NESTED = 0x20000000u;  // object is a tree of its own (OBJ_SUB_BVH)
+constexpr uint32_t LEAF_INDEX_MASK = 0x1FFFFFFFu;
 
 template <class R> struct alignas(16) DLink {  // 32 B (float) / 64 B (double)
   R bmin[3];

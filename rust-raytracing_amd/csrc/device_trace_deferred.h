@@ -443,6 +443,98 @@ RT_DEV bool traverse_flat(const SceneView<float, C>& sv, int start, const Ray<fl
   return true;
 }
 
+// Single precision, per-lane walk with the record deferred: the walk keeps (t, leaf, side, holder of the nested tree) and builds
+// the HitRecord once.  Apart from using far fewer registers than carrying a full record through two tree levels, it performs
+// the tests of traverse_lane.  (The stale (u, v) a moving sphere or a medium inherits in the reference is not reproduced here;
+// the double-precision kernels, which are the ones compared field by field, keep the eager walk.)
+template <class C>
+RT_DEV bool traverse_lane_deferred(const SceneView<float, C>& sv, int start, const Ray<float>& ray, float t_min, float t_max, Rec<float>& rec,
+                                   Stream& media, Origin org) {
+  const LaneBoxTest<float> box(ray);
+  RayInv<float> ri(ray.d);
+  ri.inv = box.inv;
+  float closest = t_max;
+  int best_leaf = -1, best_side = -1, best_holder = -1;
+  int i = start;
+  while (i >= 0) {
+    DLink<float> lk = sv.link(i);
+    while (!(lk.hit & LEAF_FLAG)) {
+      i = box.hit(lk, ray, t_min, closest) ? (int)lk.hit : lk.miss;
+      if (i < 0) break;
+      lk = sv.link(i);
+    }
+    if (i < 0) break;
+    const int obj = (int)(lk.hit & LEAF_INDEX_MASK);
+    bool nested = false;
+    if constexpr (C::has(F_NESTED)) {
+      if (lk.hit & LEAF_NESTED) {
+        nested = true;
+        const DObject<float> ob = sv.object(obj);
+        Ray<float> moved, local;
+        to_local(ob, ray, moved, local);
+        const LaneBoxTest<float> lbox(local);
+        RayInv<float> rl(local.d);
+        rl.inv = lbox.inv;
+        int j = ob.sub_root;
+        while (j >= 0) {
+          DLink<float> nl = sv.link(j);
+          while (!(nl.hit & LEAF_FLAG)) {
+            j = lbox.hit(nl, local, t_min, closest) ? (int)nl.hit : nl.miss;
+            if (j < 0) break;
+            nl = sv.link(j);
+          }
+          if (j < 0) break;
+          float t;
+          int side;
+          if (leaf_t<float, C>(sv, nl.hit, local, rl, t_min, closest, media, org, t, side)) {
+            closest = t;
+            best_leaf = (int)(nl.hit & LEAF_INDEX_MASK);
+            best_side = side;
+            best_holder = obj;
+          }
+          j = nl.miss;
+        }
+      }
+    }
+    if (!nested) {
+      float t;
+      int side;
+      if (leaf_t<float, C>(sv, lk.hit, ray, ri, t_min, closest, media, org, t, side)) {
+        closest = t;
+        best_leaf = obj;
+        best_side = side;
+        best_holder = -1;
+      }
+    }
+    i = lk.miss;
+  }
+  if (best_leaf < 0) return false;
+  if constexpr (C::has(F_NESTED)) {
+    if (best_holder >= 0) {  // record in the space of the nested tree, then back out through its holder (src/hittable.rs:146-148,229-239)
+      const DObject<float> ob = sv.objects_lane[best_holder];
+      Ray<float> moved, local;
+      to_local(ob, ray, moved, local);
+      finalize_hit<float, C>(sv, local, closest, best_leaf, best_side, rec);
+      if (ob.flags & OBJ_ROTATE_Y) {
+        V3<float> p = rec.p, n = rec.n;
+        p.x = ob.cos_theta * rec.p.x + ob.sin_theta * rec.p.z;
+        p.z = -ob.sin_theta * rec.p.x + ob.cos_theta * rec.p.z;
+        n.x = ob.cos_theta * rec.n.x + ob.sin_theta * rec.n.z;
+        n.z = -ob.sin_theta * rec.n.x + ob.cos_theta * rec.n.z;
+        rec.p = p;
+        rec.set_face_normal(local.d, n);
+      }
+      if (ob.flags & OBJ_TRANSLATE) {
+        rec.p = rec.p + V3<float>(ob.offset[0], ob.offset[1], ob.offset[2]);
+        rec.set_face_normal(moved.d, rec.n);
+      }
+      return true;
+    }
+  }
+  finalize_hit<float, C>(sv, ray, closest, best_leaf, best_side, rec);
+  return true;
+}
+
 // world.hit(ray, t_min, t_max, rec).  May be called from divergent code: lanes without a ray simply do not take part.
 template <class R, class C>
 RT_DEV bool closest_hit(const SceneView<R, C>& sv, int root, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
@@ -452,7 +544,8 @@ RT_DEV bool closest_hit(const SceneView<R, C>& sv, int root, const Ray<R>& ray, 
     }
     return traverse_uniform<R, C>(sv, root, ray, t_min, t_max, rec, media, org);
   } else {
-    return traverse_lane<R, C, 0>(sv, root, ray, t_min, t_max, rec, media, org);
+    if constexpr (sizeof(R) == sizeof(float)) return traverse_lane_deferred<C>(sv, root, ray, t_min, t_max, rec, media, org);
+    else return traverse_lane<R, C, 0>(sv, root, ray, t_min, t_max, rec, media, org);
   }
 }
 

@@ -39,7 +39,7 @@ struct LinkBuilder {
 
   int leaf(int obj, int next, int depth, int tree) {
     TmpLink l{};
-    l.hit = LEAF_FLAG | (simple(obj) ? LEAF_SIMPLE : 0u) | (uint32_t)obj;
+    l.hit = LEAF_FLAG | (simple(obj) ? LEAF_SIMPLE : 0u) | ((s.objects[obj].flags & RT_OBJ_SUB_BVH) ? LEAF_NESTED : 0u) | (uint32_t)obj;
     l.miss = next;
     l.depth = depth; l.tree = tree;
     links.push_back(l);
