@@ -14,7 +14,8 @@
 // (aabb.rs:70-83) which this oracle reproduces (tests/test_oracle_golden.py).
 // Everything the reference draws from `rand::thread_rng()` (OS-seeded ChaCha12)
 // is non-reproducible by design, so the oracle draws from a counter-based
-// Philox4x32-10 stream instead (same distributions, same call order).  All
+// Philox4x32-10 stream instead (same distributions; every draw has a fixed
+// address in the stream of its (pixel, sample, bounce), see Stream).  All
 // random-number-dependent outputs are therefore "parity unpinned" against the
 // Rust binary and pinned only statistically (committed sample renders).
 //
