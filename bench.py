@@ -194,6 +194,17 @@ def main():
                 traffic = t["bytes_per_frame"] * (args.spp / t["spp"]) * (s1 - s0) / args.spp / (launches / max(1, args.steps))
         except (OSError, KeyError):
             pass
+        issue = None
+        try:  # counters of the same kernel on the headline frame, collected by tools/profile_round.sh (separate rocprofv3 passes)
+            with open(os.path.join(REPO, "profiles", "r1_pmc.json")) as f:
+                k = json.load(f)["kernels"].get("k_paths_persistent", {})
+            if persistent and (args.scene, args.precision) == ("cornell-box", "f32") and "valu_insts_per_simd_cycle" in k:
+                issue = {"valu_insts_per_simd_cycle": k["valu_insts_per_simd_cycle"], "salu_insts_per_cu_cycle": k.get("salu_insts_per_cu_cycle"),
+                         "lanes_active_of_64": k.get("lanes_active_per_valu_cycle"), "source": "profiles/r1_pmc.json",
+                         "note": "the issue-rate microbenchmark (profiles/valu_microbench.txt) sustains 0.40 f32 FMAs and about 0.25-0.33 "
+                                 "integer/compare/select instructions per SIMD cycle"}
+        except (OSError, KeyError, ValueError):
+            pass
         if fpr is not None and bounce_ms > 0:
             achieved = fpr * rays / (bounce_ms * 1e-3) / 1e12
             peak = VALU_PEAK_F64_TFLOPS if args.precision == "f64" else VALU_PEAK_TFLOPS
@@ -203,7 +214,7 @@ def main():
             out["roofline"] = {
                 "bound": "valu", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                 "flops_per_ray": fpr, "kernel": "k_paths_persistent" if persistent else ("k_bounce_fused" if args.pipeline == "fused" else "k_trace+k_shade"),
-                "avg_launch_ms": bounce_ms / max(1.0, launches), "launches": launches,
+                "avg_launch_ms": bounce_ms / max(1.0, launches), "launches": launches, "issue": issue,
                 "note": "no dense contraction on this path (MFMA unused by design) and the scene is cache resident, so the vector ALU bounds it; "
                         "peak is the FP32 (FP64) vector FMA peak; hbm = the same launches against the HBM roofline",
                 "hbm": {"bound": "hbm", "achieved": qb * rays / (bounce_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
