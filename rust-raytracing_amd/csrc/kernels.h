@@ -335,7 +335,26 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : 1) void k
       hit = closest_hit<R, C>(sv, sc.root_link, st.ray, (R)0.001, Lim<R>::inf(), rec, media, st.org);
     }
     RT_STAMP(1);
-    if (active) active = continue_path<R, C>(sv, sc, fp, st, bounce, hit, rec, accum);
+    if (active) {
+      if (!hit) {
+        add_radiance(accum, st.pixel, st.thr * background_color<R, C>(sc.background, st.ray.d));
+        active = false;
+      } else {
+        Stream rng(fp.seed, st.pixel, st.sample, bounce, STAGE_SCATTER);
+        V3<R> emitted, attenuation;
+        Ray<R> scattered;
+        const bool alive = shade_hit<R, C>(sv, st.ray, rec, rng, emitted, attenuation, scattered);
+        add_radiance(accum, st.pixel, st.thr * emitted);
+        ++bounce;
+        if (alive && bounce < fp.max_depth) {  // ray_color(depth == 0) contributes nothing (src/render.rs:151-153)
+          st.thr = st.thr * attenuation;
+          st.ray = scattered;
+          st.org = Origin(rec.leaf, rec.side);
+        } else {
+          active = false;
+        }
+      }
+    }
     RT_STAMP(2);
   }
   RT_STAMP_FLUSH(ray_count);
