@@ -74,10 +74,7 @@ template <class R> RT_DEV V3<R> refract(V3<R> uv, V3<R> n, R etai_over_etat) {  
 RT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t& o0, uint32_t& o1,
                           uint32_t& o2, uint32_t& o3) {
 #pragma unroll
-#ifndef RT_X_ROUNDS
-#define RT_X_ROUNDS 10
-#endif
-  for (int r = 0; r < RT_X_ROUNDS; ++r) {
+  for (int r = 0; r < 10; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -181,22 +178,17 @@ template <class R> RT_DEV V3<R> point_of(uint32_t w0, uint32_t w1, uint32_t l0, 
   return V3<R>(coord_of(xi, l0 >> 1, (R)0), coord_of(yi, l1 >> 1, (R)0), coord_of(zi, l2 >> 1, (R)0));
 }
 RT_DEV V3<float> random_in_unit_sphere(const Stream& s, float) {
-#ifdef RT_X_BOUND
-  for (uint32_t b = 0; b < 32u; ++b) {
-#else
   for (uint32_t b = 0;; ++b) {
-#endif
     uint32_t h[4];
     s.hi(b, h);
     V3<float> p = point_of<float>(h[0], h[1], 0u, 0u, 0u);
-#ifdef RT_X_NOREJECT
+#ifdef RT_DIAG_ACCEPT_FIRST  // diagnostic build only: cost of the loop beyond its first candidate (changes the images)
     return p;
 #endif
     if (length_squared(p) < 1.0f) return p;
     p = point_of<float>(h[2], h[3], 0u, 0u, 0u);
     if (length_squared(p) < 1.0f) return p;
   }
-  return V3<float>(0.5f, 0.0f, 0.0f);
 }
 // Double build: the high fields alone decide all but a sliver of candidates (the low fields move a coordinate by less than
 // 2^-20, the squared length by less than 5.8e-6), so the low block is fetched once, for the candidate that passes that test.
