@@ -285,28 +285,6 @@ template <class R> struct PathFeeder {
   }
 };
 
-// What ray_color does with the result of world.hit (src/render.rs:159-176): background on a miss, else emitted light and the
-// scattered ray.  Returns whether the path goes on; `bounce` counts the closest-hit queries made so far.
-template <class R, class C>
-RT_DEV bool continue_path(const SceneView<R, C>& sv, const DeviceScene<R>& sc, const FrameParams& fp, PathState<R>& st, uint32_t& bounce, bool hit,
-                          Rec<R>& rec, R* accum) {
-  if (!hit) {
-    add_radiance(accum, st.pixel, st.thr * background_color<R, C>(sc.background, st.ray.d));
-    return false;
-  }
-  Stream rng(fp.seed, st.pixel, st.sample, bounce, STAGE_SCATTER);
-  V3<R> emitted, attenuation;
-  Ray<R> scattered;
-  const bool alive = shade_hit<R, C>(sv, st.ray, rec, rng, emitted, attenuation, scattered);
-  add_radiance(accum, st.pixel, st.thr * emitted);
-  ++bounce;
-  if (!(alive && bounce < fp.max_depth)) return false;  // ray_color(depth == 0) contributes nothing (src/render.rs:151-153)
-  st.thr = st.thr * attenuation;
-  st.ray = scattered;
-  st.org = Origin(rec.leaf, rec.side);
-  return true;
-}
-
 // Presets with nested trees want 250 registers; asking for four waves per SIMD (128 registers, some spills) is the faster trade.
 template <class R, class C>
 __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : 1) void k_paths_persistent(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
@@ -399,7 +377,26 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : RT_STEP_W
   for (;;) {
     const unsigned long long idle = __ballot(i < 0);
     if ((uint32_t)__popcll(idle) >= kRestartLanes || idle == ~0ull) {
-      if (i < 0 && active) active = continue_path<R, C>(sv, sc, fp, st, bounce, any, rec, accum);
+      if (i < 0 && active) {
+        if (!any) {
+          add_radiance(accum, st.pixel, st.thr * background_color<R, C>(sc.background, st.ray.d));
+          active = false;
+        } else {
+          Stream rng(fp.seed, st.pixel, st.sample, bounce, STAGE_SCATTER);
+          V3<R> emitted, attenuation;
+          Ray<R> scattered;
+          const bool alive = shade_hit<R, C>(sv, st.ray, rec, rng, emitted, attenuation, scattered);
+          add_radiance(accum, st.pixel, st.thr * emitted);
+          ++bounce;
+          if (alive && bounce < fp.max_depth) {  // ray_color(depth == 0) contributes nothing (src/render.rs:151-153)
+            st.thr = st.thr * attenuation;
+            st.ray = scattered;
+            st.org = Origin(rec.leaf, rec.side);
+          } else {
+            active = false;
+          }
+        }
+      }
       feeder.refill(sc, fp, total_paths, path_cursor, st, bounce, active);
       const bool start = i < 0 && active;
       n_rays += (unsigned long long)__popcll(__ballot(start));
