@@ -79,7 +79,10 @@ template <class R> struct DBackground {  // src/color.rs:35-39
 struct BlobLayout {
   uint32_t links_off, shapes_off, objects_off, materials_off, textures_off, perlins_off, flat_off, total_bytes;
   uint32_t n_links, n_objects, n_materials, n_textures, n_perlins;
-  uint32_t n_flat;  // > 0: the leaf words of the tree in visiting order follow at flat_off (single-precision small scenes)
+  // Single-precision small scenes (flat_mode != 0): the tree's leaves as two lists.  Plain rectangles, grouped by their constant
+  // axis (n_frect[0] YZ, [1] XZ, [2] XY), as FlatRect records at frect_off; every other leaf as its leaf word, in visiting order,
+  // at flat_off (n_flat of them).
+  uint32_t n_flat, flat_mode, frect_off, n_frect[3];
 };
 
 template <class R> struct DeviceScene {
@@ -94,6 +97,11 @@ template <class R> struct DeviceScene {
 };
 
 // ---------------------------------------------------------------------------------------------
+struct alignas(16) FlatRect {  // a plain rectangle ready for the test: plane coordinate, in-plane bounds, object index
+  float k, a0, a1, b0, b1;
+  int32_t obj, pad0, pad1;
+};
+
 // Kernel configuration: which parts of the scene grammar a kernel instantiation carries, and how it walks the tree.
 // A scene is rendered by the smallest preset that covers its contents; code for absent features is not compiled
 // in, which is what keeps the register count (and with it the waves per SIMD) of the common cases low.
@@ -184,7 +192,9 @@ template <class R, class C> struct SceneView {
   const DShape<R>* shapes;
   const DObject<R>* objects;
   const uint32_t* flat;            // leaf words in visiting order (global memory, scalar loads), n_flat of them
-  uint32_t n_flat;
+  uint32_t n_flat, flat_mode;
+  const FlatRect* frect;           // plain rectangles by axis (global memory, scalar loads)
+  uint32_t n_frect[3];
   const DShape<R>* shapes_lane;    // the same records where a lane gathers them with an index of its own (LDS in WALK_UNIFORM)
   const DObject<R>* objects_lane;
   const DMaterial<R>* materials;
@@ -263,6 +273,9 @@ template <class R, class C> RT_DEV SceneView<R, C> make_view(const DeviceScene<R
   v.images = sc.images;
   v.flat = reinterpret_cast<const uint32_t*>(g + sc.lay.flat_off);
   v.n_flat = sc.lay.n_flat;
+  v.flat_mode = sc.lay.flat_mode;
+  v.frect = reinterpret_cast<const FlatRect*>(g + sc.lay.frect_off);
+  for (int k = 0; k < 3; ++k) v.n_frect[k] = sc.lay.n_frect[k];
   return v;
 }
 

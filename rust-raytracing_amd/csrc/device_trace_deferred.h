@@ -341,8 +341,9 @@ RT_DEV bool box_slab_span(const DShape<float>& s, const Ray<float>& ray, const R
   return tn <= tf;
 }
 
-// Single precision, scenes of a few leaves: every leaf is tested, in the order the tree would visit them, with the same
-// shrinking t_max; only the root box is kept as an early out.  A box test can only skip leaves the ray does not hit (up to
+// Single precision, scenes of a few leaves: every leaf is tested with the same shrinking t_max - plain rectangles first,
+// grouped by axis, then the other leaves in the order the tree would visit them (among exactly coincident surfaces the last
+// one tested is reported, so at shared edges the order shows); only the root box is kept as an early out.  A box test can only skip leaves the ray does not hit (up to
 // rounding at grazing incidence, which the single-precision tolerance covers), and with incoherent rays every wave visits
 // every entry anyway, so the inner box tests and the per-lane position in the tree are pure overhead here.
 template <class C>
@@ -356,6 +357,26 @@ RT_DEV bool traverse_flat(const SceneView<float, C>& sv, int start, const Ray<fl
   RT_STAMP_IN(media, 3);
   if (inside) {
     const int org_leaf = org.leaf(), org_side = org.side();
+    // plain rectangles, one list per constant axis: one record fetch and a dozen vector instructions each
+    const FlatRect* fr = sv.frect;
+    for (uint32_t k = 0; k < sv.n_frect[0]; ++k, ++fr) {
+      const FlatRect r = load_uniform(fr);
+      float t;
+      const bool ok = rect_fast<0>(r.a0, r.a1, r.b0, r.b1, r.k, ray, ri, t_min, closest, t) & (org_leaf != r.obj);
+      closest = ok ? t : closest; best_leaf = ok ? r.obj : best_leaf; best_side = ok ? -1 : best_side;
+    }
+    for (uint32_t k = 0; k < sv.n_frect[1]; ++k, ++fr) {
+      const FlatRect r = load_uniform(fr);
+      float t;
+      const bool ok = rect_fast<1>(r.a0, r.a1, r.b0, r.b1, r.k, ray, ri, t_min, closest, t) & (org_leaf != r.obj);
+      closest = ok ? t : closest; best_leaf = ok ? r.obj : best_leaf; best_side = ok ? -1 : best_side;
+    }
+    for (uint32_t k = 0; k < sv.n_frect[2]; ++k, ++fr) {
+      const FlatRect r = load_uniform(fr);
+      float t;
+      const bool ok = rect_fast<2>(r.a0, r.a1, r.b0, r.b1, r.k, ray, ri, t_min, closest, t) & (org_leaf != r.obj);
+      closest = ok ? t : closest; best_leaf = ok ? r.obj : best_leaf; best_side = ok ? -1 : best_side;
+    }
     for (uint32_t k = 0; k < sv.n_flat; ++k) {
       const uint32_t word = load_uniform_u32(sv.flat + k);
       const int obj = (int)(word & LEAF_INDEX_MASK);
@@ -540,7 +561,7 @@ template <class R, class C>
 RT_DEV bool closest_hit(const SceneView<R, C>& sv, int root, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
   if constexpr (C::walk == WALK_UNIFORM) {
     if constexpr (sizeof(R) == sizeof(float)) {
-      if (sv.n_flat != 0u) return traverse_flat<C>(sv, root, ray, t_min, t_max, rec, media, org);
+      if (sv.flat_mode != 0u) return traverse_flat<C>(sv, root, ray, t_min, t_max, rec, media, org);
     }
     return traverse_uniform<R, C>(sv, root, ray, t_min, t_max, rec, media, org);
   } else {

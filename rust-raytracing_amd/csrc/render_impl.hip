@@ -60,11 +60,36 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
       if (l.hit & LEAF_FLAG) flat.push_back(l.hit);
     if (flat.size() > kFlatMaxLeaves) flat.clear();
   }
+  // plain rectangles leave the list of leaf words for per-axis lists of ready-made records
+  std::vector<FlatRect> frects[3];
+  std::vector<uint32_t> others;
+  for (uint32_t word : flat) {
+    const int obj = (int)(word & LEAF_INDEX_MASK);
+    const rt_object& o = s.objects[obj];
+    const rt_shape& sh = s.shapes[o.geom];
+    const int axis = sh.tag == RT_SHAPE_RECT_YZ ? 0 : sh.tag == RT_SHAPE_RECT_XZ ? 1 : sh.tag == RT_SHAPE_RECT_XY ? 2 : -1;
+    if ((word & LEAF_SIMPLE) && axis >= 0 && !getenv("RTAMD_NO_FLAT_RECTS")) {
+      FlatRect r{};
+      r.a0 = (float)sh.p[0]; r.a1 = (float)sh.p[1]; r.b0 = (float)sh.p[2]; r.b1 = (float)sh.p[3]; r.k = (float)sh.p[4];
+      r.obj = obj;
+      frects[axis].push_back(r);
+    } else {
+      others.push_back(word);
+    }
+  }
+  lay.flat_mode = flat.empty() ? 0u : 1u;
   lay.flat_off = off; off = align16(off + (uint32_t)(kFlatMaxLeaves * sizeof(uint32_t)));
-  lay.n_flat = (uint32_t)flat.size();
+  lay.n_flat = (uint32_t)others.size();
+  lay.frect_off = off; off = align16(off + (uint32_t)(kFlatMaxLeaves * sizeof(FlatRect)));
+  for (int k = 0; k < 3; ++k) lay.n_frect[k] = (uint32_t)frects[k].size();
   lay.total_bytes = off;
   std::vector<uint8_t> blob(off, 0);
-  if (!flat.empty()) memcpy(blob.data() + lay.flat_off, flat.data(), flat.size() * sizeof(uint32_t));
+  if (!others.empty()) memcpy(blob.data() + lay.flat_off, others.data(), others.size() * sizeof(uint32_t));
+  {
+    FlatRect* fr = reinterpret_cast<FlatRect*>(blob.data() + lay.frect_off);
+    for (int k = 0; k < 3; ++k)
+      for (const FlatRect& r : frects[k]) *fr++ = r;
+  }
   auto* L = reinterpret_cast<DLink<R>*>(blob.data() + lay.links_off);
   for (size_t i = 0; i < links.size(); ++i) {
     for (int k = 0; k < 3; ++k) { L[i].bmin[k] = round_down<R>(links[i].bmin[k]); L[i].bmax[k] = round_up<R>(links[i].bmax[k]); }
