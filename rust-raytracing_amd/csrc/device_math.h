@@ -111,6 +111,16 @@ struct Stream {
   RT_DEV void hi(uint32_t block, uint32_t h[4]) const { philox4x32_10(block, c1, c2, c3, k0, k1, h[0], h[1], h[2], h[3]); }
   RT_DEV void lo(uint32_t block, uint32_t l[4]) const { philox4x32_10(block, c1 | (1u << 20), c2, c3, k0, k1, l[0], l[1], l[2], l[3]); }
 };
+// A stream whose H block 0 is already computed.  The path kernels evaluate that block once per turn for all lanes - a scatter
+// stream in the lanes that continue a path, a camera stream in the lanes that start one - so both uses share one pass of Philox.
+struct PrimedStream : Stream {
+  uint32_t h0[4];
+  RT_DEV explicit PrimedStream(const Stream& s) : Stream(s) { Stream::hi(0u, h0); }
+  RT_DEV void hi(uint32_t block, uint32_t h[4]) const {
+    if (block == 0u) { h[0] = h0[0]; h[1] = h0[1]; h[2] = h0[2]; h[3] = h0[3]; }
+    else Stream::hi(block, h);
+  }
+};
 
 // rand 0.8.5 value conversions: Standard f64 keeps 53 bits; gen_range builds a 52-bit mantissa in [1,2) - 1 and scales it
 // (a result that rounds up to `hi`, probability about 2^-52, takes the largest value below hi).
@@ -133,13 +143,13 @@ template <class R> RT_DEV R signed_unit_of(uint32_t h, uint32_t l) { return m01_
 template <class R> struct Block;
 template <> struct Block<float> {
   uint32_t h[4];
-  RT_DEV Block(const Stream& s, uint32_t b) { s.hi(b, h); }
+  template <class S> RT_DEV Block(const S& s, uint32_t b) { s.hi(b, h); }
   RT_DEV float u01(int j) const { return u01_of(h[j], 0u, 0.0f); }
   RT_DEV float range(int j, float lo, float hi) const { return range_of<float>(h[j], 0u, lo, hi); }
 };
 template <> struct Block<double> {
   uint32_t h[4], l[4];
-  RT_DEV Block(const Stream& s, uint32_t b) { s.hi(b, h); s.lo(b, l); }
+  template <class S> RT_DEV Block(const S& s, uint32_t b) { s.hi(b, h); s.lo(b, l); }
   RT_DEV double u01(int j) const { return u01_of(h[j], l[j], 0.0); }
   RT_DEV double range(int j, double lo, double hi) const { return range_of<double>(h[j], l[j], lo, hi); }
 };
@@ -177,7 +187,7 @@ template <class R> RT_DEV V3<R> point_of(uint32_t w0, uint32_t w1, uint32_t l0, 
   fields21(w0, w1, xi, yi, zi);
   return V3<R>(coord_of(xi, l0 >> 1, (R)0), coord_of(yi, l1 >> 1, (R)0), coord_of(zi, l2 >> 1, (R)0));
 }
-RT_DEV V3<float> random_in_unit_sphere(const Stream& s, float) {
+template <class S> RT_DEV V3<float> random_in_unit_sphere(const S& s, float) {
   for (uint32_t b = 0;; ++b) {
     uint32_t h[4];
     s.hi(b, h);
@@ -192,7 +202,7 @@ RT_DEV V3<float> random_in_unit_sphere(const Stream& s, float) {
 }
 // Double build: the high fields alone decide all but a sliver of candidates (the low fields move a coordinate by less than
 // 2^-20, the squared length by less than 5.8e-6), so the low block is fetched once, for the candidate that passes that test.
-RT_DEV V3<double> random_in_unit_sphere(const Stream& s, double) {
+template <class S> RT_DEV V3<double> random_in_unit_sphere(const S& s, double) {
   uint32_t c = 0;
   uint32_t h[4] = {0u, 0u, 0u, 0u};
   for (;;) {
@@ -210,16 +220,16 @@ RT_DEV V3<double> random_in_unit_sphere(const Stream& s, double) {
     ++c;
   }
 }
-template <class R> RT_DEV V3<R> random_in_unit_sphere(const Stream& s) { return random_in_unit_sphere(s, (R)0); }
+template <class R, class S> RT_DEV V3<R> random_in_unit_sphere(const S& s) { return random_in_unit_sphere(s, (R)0); }
 // src/vec3.rs:90-92.  Single precision scales by the hardware reciprocal square root (1 ulp) instead of sqrt then divide.
-RT_DEV V3<double> random_unit_vector(const Stream& s, double) { return unit_vector(random_in_unit_sphere<double>(s)); }
-RT_DEV V3<float> random_unit_vector(const Stream& s, float) {
+template <class S> RT_DEV V3<double> random_unit_vector(const S& s, double) { return unit_vector(random_in_unit_sphere<double>(s)); }
+template <class S> RT_DEV V3<float> random_unit_vector(const S& s, float) {
   V3<float> p = random_in_unit_sphere<float>(s);
   return __builtin_amdgcn_rsqf(length_squared(p)) * p;
 }
-template <class R> RT_DEV V3<R> random_unit_vector(const Stream& s) { return random_unit_vector(s, (R)0); }
+template <class R, class S> RT_DEV V3<R> random_unit_vector(const S& s) { return random_unit_vector(s, (R)0); }
 // src/vec3.rs:103-111 on the camera stream: candidate c is block 1 + c.
-template <class R> RT_DEV V3<R> random_in_unit_disk(const Stream& s) {
+template <class R, class S> RT_DEV V3<R> random_in_unit_disk(const S& s) {
   for (uint32_t c = 0;; ++c) {
     Block<R> b(s, 1u + c);
     V3<R> p(b.range(0, (R)-1, (R)1), b.range(1, (R)-1, (R)1), (R)0);

@@ -91,8 +91,8 @@ template <class R> RT_DEV R schlick_reflectance(R cosine, R ref_idx) {  // src/m
 
 // material.emitted + material.scatter for a final hit record (src/render.rs:162-176).
 // Returns true when a scattered ray exists; `emitted` is always written.
-template <class R, class C>
-RT_DEV bool shade_hit(const SceneView<R, C>& sv, const Ray<R>& ray_in, Rec<R>& rec, Stream& rng, V3<R>& emitted, V3<R>& attenuation,
+template <class R, class C, class S>
+RT_DEV bool shade_hit(const SceneView<R, C>& sv, const Ray<R>& ray_in, Rec<R>& rec, const S& rng, V3<R>& emitted, V3<R>& attenuation,
                       Ray<R>& scattered) {
   if constexpr (C::has(F_UV)) rec.finish_uv();
   const DMaterial<R> m = sv.materials[rec.mat];
@@ -165,12 +165,12 @@ RT_DEV float jitter_coord(uint32_t i, float u, uint32_t wm1) { return ((float)i 
 
 // Primary ray of (pixel, sample): src/render.rs:230-234 then Camera::get_ray (src/camera.rs:62-72).
 // pixel = y * W + x with y counted from the top row; the reference's j is H - 1 - y.
-template <class R>
-RT_DEV Ray<R> primary_ray(const DCamera<R>& cam, uint32_t W, uint32_t H, uint32_t pixel, uint32_t sample, uint64_t seed) {
+// `rng` is the camera stream of (pixel, sample).
+template <class R, class S>
+RT_DEV Ray<R> primary_ray(const DCamera<R>& cam, uint32_t W, uint32_t H, uint32_t pixel, const S& rng) {
   uint32_t y, i;
   pixel_row_col(pixel, W, y, i);
   uint32_t j = H - 1u - y;
-  const Stream rng(seed, pixel, sample, 0u, STAGE_CAMERA);
   const Block<R> jitter(rng, 0u);
   R u_rand = jitter.u01(0);
   R v_rand = jitter.u01(1);
@@ -185,6 +185,10 @@ RT_DEV Ray<R> primary_ray(const DCamera<R>& cam, uint32_t W, uint32_t H, uint32_
   ray.time = jitter.range(2, cam.t_open, cam.t_close);
   ray.o = cam.origin + offset;
   return ray;
+}
+template <class R>
+RT_DEV Ray<R> primary_ray(const DCamera<R>& cam, uint32_t W, uint32_t H, uint32_t pixel, uint32_t sample, uint64_t seed) {
+  return primary_ray<R>(cam, W, H, pixel, Stream(seed, pixel, sample, 0u, STAGE_CAMERA));
 }
 
 // color_to_rgb (src/color.rs:14-27); Rust `as u8` saturates and maps NaN to 0.

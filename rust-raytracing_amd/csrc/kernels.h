@@ -246,7 +246,8 @@ template <class R> struct PathFeeder {
   bool exhausted = false;  // the global cursor has passed total_paths
 
   // Gives every lane with `!active` a new path while there are any; lanes that receive one become active with bounce = 0.
-  RT_DEV void refill(const DeviceScene<R>& sc, const FrameParams& fp, unsigned long long total_paths, unsigned long long* path_cursor,
+  // MAKE_RAY = false leaves st.ray for the caller to fill in.
+  template <bool MAKE_RAY = true> RT_DEV void refill(const DeviceScene<R>& sc, const FrameParams& fp, unsigned long long total_paths, unsigned long long* path_cursor,
                      PathState<R>& st, uint32_t& bounce, bool& active) {
     const uint32_t lane = threadIdx.x & 63u;
     unsigned long long dead = __ballot(!active);
@@ -271,7 +272,7 @@ template <class R> struct PathFeeder {
       if (!active && rank < n_take) {
         st.pixel = pixel + rank;
         st.sample = fp.sample_base + sample;
-        st.ray = primary_ray<R>(sc.camera, fp.width, fp.height, st.pixel, st.sample, fp.seed);
+        if constexpr (MAKE_RAY) st.ray = primary_ray<R>(sc.camera, fp.width, fp.height, st.pixel, st.sample, fp.seed);
         st.thr = V3<R>((R)1, (R)1, (R)1);
         st.org = Origin();
         bounce = 0;
@@ -293,47 +294,61 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : 1) void k
   const SceneView<R, C> sv = make_view<R, C>(sc, lds);
   const uint32_t lane = threadIdx.x & 63u;
   PathFeeder<R> feeder;
-  bool active = false;
+  bool active = false;   // the lane holds a path
+  bool hit = false;      // ... whose last ray hit something: `rec` waits to be shaded
   uint32_t bounce = 0;
   unsigned long long n_rays = 0;
   PathState<R> st;
+  Rec<R> rec;
   RT_STAMP_INIT();
+  // One turn: paths that end at their last hit are closed, their lanes take new paths, then ONE evaluation of Philox serves
+  // the scatter draw of the continuing lanes and the pixel jitter of the new ones, and all lanes trace their next ray.
   for (;;) {
     RT_STAMP(6);
-    feeder.refill(sc, fp, total_paths, path_cursor, st, bounce, active);
-    RT_STAMP(0);
-    const unsigned long long live = __ballot(active);
-    if (live == 0ull) break;
-    n_rays += (unsigned long long)__popcll(live);
-    bool hit = false;
-    Rec<R> rec;
+    bool to_scatter = false;
     if (active) {
+      if (!hit) {
+        add_radiance(accum, st.pixel, st.thr * background_color<R, C>(sc.background, st.ray.d));
+        active = false;
+      } else if (sv.materials[rec.mat].tag == MAT_LIGHT) {  // emits, never scatters (src/material.rs:148-167)
+        V3<R> emitted, attenuation;
+        Ray<R> scattered;
+        shade_hit<R, C>(sv, st.ray, rec, Stream(fp.seed, st.pixel, st.sample, bounce, STAGE_SCATTER), emitted, attenuation, scattered);
+        add_radiance(accum, st.pixel, st.thr * emitted);
+        active = false;
+      } else if (bounce + 1u >= fp.max_depth) {  // ray_color(depth == 0) contributes nothing (src/render.rs:151-153)
+        active = false;
+      } else {
+        to_scatter = true;
+      }
+    }
+    feeder.template refill<false>(sc, fp, total_paths, path_cursor, st, bounce, active);
+    RT_STAMP(0);
+    if (__ballot(active) == 0ull) break;
+    const PrimedStream rng(Stream(fp.seed, st.pixel, st.sample, bounce, to_scatter ? STAGE_SCATTER : STAGE_CAMERA));
+    if (to_scatter) {
+      V3<R> emitted, attenuation;
+      Ray<R> scattered;
+      const bool alive = shade_hit<R, C>(sv, st.ray, rec, rng, emitted, attenuation, scattered);
+      add_radiance(accum, st.pixel, st.thr * emitted);
+      ++bounce;
+      st.thr = st.thr * attenuation;
+      st.ray = scattered;
+      st.org = Origin(rec.leaf, rec.side);
+      active = alive;
+    } else if (active) {
+      st.ray = primary_ray<R>(sc.camera, fp.width, fp.height, st.pixel, rng);
+    }
+    RT_STAMP(2);
+    n_rays += (unsigned long long)__popcll(__ballot(active));
+    hit = false;
+    if (active) {
+      rec = Rec<R>();
       Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
       RT_STAMP_ATTACH(media);
       hit = closest_hit<R, C>(sv, sc.root_link, st.ray, (R)0.001, Lim<R>::inf(), rec, media, st.org);
     }
     RT_STAMP(1);
-    if (active) {
-      if (!hit) {
-        add_radiance(accum, st.pixel, st.thr * background_color<R, C>(sc.background, st.ray.d));
-        active = false;
-      } else {
-        Stream rng(fp.seed, st.pixel, st.sample, bounce, STAGE_SCATTER);
-        V3<R> emitted, attenuation;
-        Ray<R> scattered;
-        const bool alive = shade_hit<R, C>(sv, st.ray, rec, rng, emitted, attenuation, scattered);
-        add_radiance(accum, st.pixel, st.thr * emitted);
-        ++bounce;
-        if (alive && bounce < fp.max_depth) {  // ray_color(depth == 0) contributes nothing (src/render.rs:151-153)
-          st.thr = st.thr * attenuation;
-          st.ray = scattered;
-          st.org = Origin(rec.leaf, rec.side);
-        } else {
-          active = false;
-        }
-      }
-    }
-    RT_STAMP(2);
   }
   RT_STAMP_FLUSH(ray_count);
   if (lane == 0u && n_rays != 0ull) atomicAdd(ray_count, n_rays);
