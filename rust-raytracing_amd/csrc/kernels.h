@@ -392,27 +392,40 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : RT_STEP_W
   for (;;) {
     const unsigned long long idle = __ballot(i < 0);
     if ((uint32_t)__popcll(idle) >= kRestartLanes || idle == ~0ull) {
+      bool to_scatter = false;
       if (i < 0 && active) {
         if (!any) {
           add_radiance(accum, st.pixel, st.thr * background_color<R, C>(sc.background, st.ray.d));
           active = false;
+        } else if (sv.materials[rec.mat].tag == MAT_LIGHT) {  // emits, never scatters (src/material.rs:148-167)
+          V3<R> emitted, attenuation;
+          Ray<R> scattered;
+          shade_hit<R, C>(sv, st.ray, rec, Stream(fp.seed, st.pixel, st.sample, bounce, STAGE_SCATTER), emitted, attenuation, scattered);
+          add_radiance(accum, st.pixel, st.thr * emitted);
+          active = false;
+        } else if (bounce + 1u >= fp.max_depth) {  // ray_color(depth == 0) contributes nothing (src/render.rs:151-153)
+          active = false;
         } else {
-          Stream rng(fp.seed, st.pixel, st.sample, bounce, STAGE_SCATTER);
+          to_scatter = true;
+        }
+      }
+      feeder.template refill<false>(sc, fp, total_paths, path_cursor, st, bounce, active);
+      if (i < 0 && active) {  // one Philox pass: scatter draw of the continuing lanes, pixel jitter of the new ones
+        const PrimedStream rng(Stream(fp.seed, st.pixel, st.sample, bounce, to_scatter ? STAGE_SCATTER : STAGE_CAMERA));
+        if (to_scatter) {
           V3<R> emitted, attenuation;
           Ray<R> scattered;
           const bool alive = shade_hit<R, C>(sv, st.ray, rec, rng, emitted, attenuation, scattered);
           add_radiance(accum, st.pixel, st.thr * emitted);
           ++bounce;
-          if (alive && bounce < fp.max_depth) {  // ray_color(depth == 0) contributes nothing (src/render.rs:151-153)
-            st.thr = st.thr * attenuation;
-            st.ray = scattered;
-            st.org = Origin(rec.leaf, rec.side);
-          } else {
-            active = false;
-          }
+          st.thr = st.thr * attenuation;
+          st.ray = scattered;
+          st.org = Origin(rec.leaf, rec.side);
+          active = alive;
+        } else {
+          st.ray = primary_ray<R>(sc.camera, fp.width, fp.height, st.pixel, rng);
         }
       }
-      feeder.refill(sc, fp, total_paths, path_cursor, st, bounce, active);
       const bool start = i < 0 && active;
       n_rays += (unsigned long long)__popcll(__ballot(start));
       if (start) {
