@@ -532,7 +532,9 @@ int orc_aabb_hit(const double mn[3], const double mx[3], const double o[3], cons
   return b.hit(r, tmin, tmax) ? 1 : 0;
 }
 void orc_sphere_uv(const double p[3], double* u, double* v) { get_sphere_uv<double>(V3<double>(p[0], p[1], p[2]), *u, *v); }
-void orc_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32_10(ctr, key, out); }
+void orc_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32(ctr, key, out); }
+void orc_philox_rounds(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4], int rounds) { philox4x32(ctr, key, out, rounds); }
+int orc_philox_stream_rounds() { return kPhiloxRounds; }
 void orc_stream_words(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t stage, int n, uint64_t* out) {
   Stream s(seed, pixel, sample, bounce, (Stage)stage);
   for (int i = 0; i < n; ++i) out[i] = s.word((uint32_t)i);

@@ -14,7 +14,7 @@
 // (aabb.rs:70-83) which this oracle reproduces (tests/test_oracle_golden.py).
 // Everything the reference draws from `rand::thread_rng()` (OS-seeded ChaCha12)
 // is non-reproducible by design, so the oracle draws from a counter-based
-// Philox4x32-10 stream instead (same distributions; every draw has a fixed
+// Philox4x32-7 stream instead (same distributions; every draw has a fixed
 // address in the stream of its (pixel, sample, bounce), see Stream).  All
 // random-number-dependent outputs are therefore "parity unpinned" against the
 // Rust binary and pinned only statistically (committed sample renders).
@@ -61,14 +61,17 @@ struct Counters {
 inline thread_local Counters g_cnt;
 
 // ---------------------------------------------------------------------------
-// Philox4x32-10 (Salmon et al., SC'11) — published constants.  Replaces
+// Philox4x32 (Salmon et al., SC'11) — published round function and constants,
+// kPhiloxRounds = 7 rounds (the smallest count the paper reports as passing
+// BigCrush; Random123 publishes known-answer vectors for 7 and for 10).  Replaces
 // rand::thread_rng (reference call sites: render.rs:226, camera.rs:69,
 // vec3.rs:20,25,104, constant_medium.rs:50, material.rs:127).
 // ---------------------------------------------------------------------------
-inline void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+constexpr int kPhiloxRounds = 7;
+inline void philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4], int rounds = kPhiloxRounds) {
   uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
   uint32_t k0 = key[0], k1 = key[1];
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < rounds; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -113,19 +116,19 @@ struct Stream {
   }
   void hi_block(uint32_t b, uint32_t out[4]) const {
     uint32_t c[4] = {b, c1, c2, c3};
-    philox4x32_10(c, key, out);
+    philox4x32(c, key, out);
   }
   void lo_block(uint32_t b, uint32_t out[4]) const {
     uint32_t c[4] = {b, c1 | (1u << 20), c2, c3};
-    philox4x32_10(c, key, out);
+    philox4x32(c, key, out);
   }
   uint64_t word(uint32_t slot) {
     uint32_t b = slot >> 2, j = slot & 3u;
     if (b != cached) {
       uint32_t ch[4] = {b, c1, c2, c3};
       uint32_t cl[4] = {b, c1 | (1u << 20), c2, c3};
-      philox4x32_10(ch, key, hi);
-      philox4x32_10(cl, key, lo);
+      philox4x32(ch, key, hi);
+      philox4x32(cl, key, lo);
       cached = b;
     }
     ++g_cnt.rng_words;

@@ -67,14 +67,18 @@ template <class R> RT_DEV V3<R> refract(V3<R> uv, V3<R> n, R etai_over_etat) {  
 }
 
 // ---------------------------------------------------------------------------------------------
-// Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11).
+// Philox4x32-7 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11): the 4x32 round function and
+// constants with seven rounds, the smallest count the paper reports as passing BigCrush (ten is its default, with extra margin).
+// A block costs two 32x32->64 multiplies per round at a quarter of the plain issue rate, and random draws are a third of this
+// kernel's instructions, so the three rounds are worth about a tenth of the frame time.
 // Stands in for rand::thread_rng() (src/render.rs:226, src/camera.rs:69, src/vec3.rs:20,25,104,
 // src/constant_medium.rs:50, src/material.rs:127).
 // ---------------------------------------------------------------------------------------------
-RT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t& o0, uint32_t& o1,
+constexpr int kPhiloxRounds = 7;
+RT_DEV void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t& o0, uint32_t& o1,
                           uint32_t& o2, uint32_t& o3) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < kPhiloxRounds; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -108,8 +112,8 @@ struct Stream {
   uint32_t k0, k1, c1, c2, c3;
   RT_DEV Stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t stage)
       : k0(pixel), k1(sample), c1(bounce | (stage << 16)), c2((uint32_t)seed), c3((uint32_t)(seed >> 32)) {}
-  RT_DEV void hi(uint32_t block, uint32_t h[4]) const { philox4x32_10(block, c1, c2, c3, k0, k1, h[0], h[1], h[2], h[3]); }
-  RT_DEV void lo(uint32_t block, uint32_t l[4]) const { philox4x32_10(block, c1 | (1u << 20), c2, c3, k0, k1, l[0], l[1], l[2], l[3]); }
+  RT_DEV void hi(uint32_t block, uint32_t h[4]) const { philox4x32(block, c1, c2, c3, k0, k1, h[0], h[1], h[2], h[3]); }
+  RT_DEV void lo(uint32_t block, uint32_t l[4]) const { philox4x32(block, c1 | (1u << 20), c2, c3, k0, k1, l[0], l[1], l[2], l[3]); }
 };
 // A stream whose H block 0 is already computed.  The path kernels evaluate that block once per turn for all lanes - a scatter
 // stream in the lanes that continue a path, a camera stream in the lanes that start one - so both uses share one pass of Philox.

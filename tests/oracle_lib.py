@@ -78,6 +78,7 @@ def lib():
         L.orc_aabb_hit.argtypes = [C.c_void_p] * 4 + [C.c_double, C.c_double]
         L.orc_sphere_uv.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_philox.argtypes = [C.c_void_p] * 3
+        L.orc_philox_rounds.argtypes = [C.c_void_p] * 3 + [C.c_int]
         L.orc_stream_words.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_pcg32_words.argtypes = [C.c_uint64, C.c_int, C.c_void_p]
         L.orc_shape_hit.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -210,6 +211,18 @@ def philox(ctr, key):
     out = np.zeros(4, dtype=np.uint32)
     lib().orc_philox(_p(c), _p(k), _p(out))
     return out
+
+
+def philox_rounds(ctr, key, rounds):
+    c = np.asarray(ctr, dtype=np.uint32)
+    k = np.asarray(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().orc_philox_rounds(_p(c), _p(k), _p(out), rounds)
+    return out
+
+
+def philox_stream_rounds():
+    return lib().orc_philox_stream_rounds()
 
 
 def stream_words(seed, pixel, sample, bounce, stage, n):

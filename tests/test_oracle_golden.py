@@ -116,11 +116,23 @@ def test_divide_into_ranges(oracle):
 
 
 def test_philox_published_vectors(oracle):
-    # Random123 known-answer vectors for philox4x32-10
-    assert [hex(x) for x in oracle.philox([0] * 4, [0] * 2)] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
-    assert [hex(x) for x in oracle.philox([0xffffffff] * 4, [0xffffffff] * 2)] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
-    assert [hex(x) for x in oracle.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])] == \
-        ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+    # Random123 known-answer vectors (kat_vectors) for philox4x32 with 10 rounds and with the 7 rounds the streams use
+    zero, ones = ([0] * 4, [0] * 2), ([0xffffffff] * 4, [0xffffffff] * 2)
+    pi = ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])
+    kat = {
+        10: [(zero, ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]),
+             (ones, ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]),
+             (pi, ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"])],
+        7: [(zero, ["0x5f6fb709", "0xd893f64", "0x4f121f81", "0x4f730a48"]),
+            (ones, ["0x5207ddc2", "0x45165e59", "0x4d8ee751", "0x8c52f662"]),
+            (pi, ["0x4dfccaba", "0x190a87f0", "0xc47362ba", "0xb6b5242a"])],
+    }
+    for rounds, cases in kat.items():
+        for (ctr, key), want in cases:
+            assert [hex(x) for x in oracle.philox_rounds(ctr, key, rounds)] == want
+    assert oracle.philox_stream_rounds() == 7
+    for (ctr, key), want in kat[7]:
+        assert [hex(x) for x in oracle.philox(ctr, key)] == want
 
 
 def test_stream_layout(oracle):
