@@ -83,6 +83,7 @@ struct BlobLayout {
   // axis (n_frect[0] YZ, [1] XZ, [2] XY), as FlatRect records at frect_off; every other leaf as its leaf word, in visiting order,
   // at flat_off (n_flat of them).
   uint32_t n_flat, flat_mode, frect_off, n_frect[3];
+  uint32_t faces_off;  // FlatFace records, six per object (flat_mode only)
 };
 
 template <class R> struct DeviceScene {
@@ -100,6 +101,15 @@ template <class R> struct DeviceScene {
 struct alignas(16) FlatRect {  // a plain rectangle ready for the test: plane coordinate, in-plane bounds, object index
   float k, a0, a1, b0, b1;
   int32_t obj, pad0, pad1;
+};
+
+// One planar side of a rectangle or box, as the record of a hit needs it (single-precision small scenes): slot 6 * object + side,
+// a rectangle's only side in slot 0.  `n` is the side's outward normal after the holder's RotateY; bits 0..3 of `flags` are the
+// holder's OBJ_* flags, bits 4..5 the side's constant axis in the shape's own frame.
+struct alignas(16) FlatFace {
+  float n[3];
+  uint32_t flags;
+  float cos_theta, sin_theta, k, pad;
 };
 
 // Kernel configuration: which parts of the scene grammar a kernel instantiation carries, and how it walks the tree.
@@ -195,6 +205,7 @@ template <class R, class C> struct SceneView {
   uint32_t n_flat, flat_mode;
   const FlatRect* frect;           // plain rectangles by axis (global memory, scalar loads)
   uint32_t n_frect[3];
+  const FlatFace* faces_lane;      // per-lane gathers (LDS)
   const DShape<R>* shapes_lane;    // the same records where a lane gathers them with an index of its own (LDS in WALK_UNIFORM)
   const DObject<R>* objects_lane;
   const DMaterial<R>* materials;
@@ -267,6 +278,7 @@ template <class R, class C> RT_DEV SceneView<R, C> make_view(const DeviceScene<R
   v.objects = reinterpret_cast<const DObject<R>*>(geom + sc.lay.objects_off);
   v.shapes_lane = reinterpret_cast<const DShape<R>*>(lane + sc.lay.shapes_off);
   v.objects_lane = reinterpret_cast<const DObject<R>*>(lane + sc.lay.objects_off);
+  v.faces_lane = reinterpret_cast<const FlatFace*>(lane + sc.lay.faces_off);
   v.materials = reinterpret_cast<const DMaterial<R>*>(shade + (sc.lay.materials_off - shade_sub));
   v.textures = reinterpret_cast<const DTexture<R>*>(shade + (sc.lay.textures_off - shade_sub));
   v.perlins = reinterpret_cast<const DPerlin<R>*>(shade + (sc.lay.perlins_off - shade_sub));

@@ -459,6 +459,36 @@ RT_DEV bool traverse_flat(const SceneView<float, C>& sv, int start, const Ray<fl
   }
   RT_STAMP_IN(media, 4);
   if (best_leaf < 0) return false;
+  if constexpr (!C::has(F_UV) && !C::has(F_SPHERE) && !C::has(F_MOVING)) {
+    // every surface here is a planar side: its record comes from the table of sides.  The normal goes through the reference's
+    // chain of set_face_normal calls - shape, RotateY (which pairs the rotated normal with the UNrotated-frame direction,
+    // src/hittable.rs:236-239), Translate (src/hittable.rs:146-148) - as signs of one vector.
+    if (best_side != SIDE_MEDIUM) {
+      const FlatFace f = sv.faces_lane[6 * best_leaf + (best_side < 0 ? 0 : best_side)];
+      const DShape<float>& s = sv.shapes_lane[best_leaf];
+      const int axis = (int)((f.flags >> 4) & 3u);
+      const V3<float> nw(f.n[0], f.n[1], f.n[2]);
+      V3<float> dl = ray.d;
+      if (f.flags & OBJ_ROTATE_Y) {
+        dl.x = f.cos_theta * ray.d.x - f.sin_theta * ray.d.z;
+        dl.z = f.sin_theta * ray.d.x + f.cos_theta * ray.d.z;
+      }
+      const float d1 = axis == 0 ? dl.x : axis == 1 ? dl.y : dl.z;
+      bool front = d1 < 0.0f;
+      float sgn = front ? 1.0f : -1.0f;
+      if (f.flags & OBJ_ROTATE_Y) { front = sgn * dot(dl, nw) < 0.0f; sgn = front ? sgn : -sgn; }
+      if (f.flags & OBJ_TRANSLATE) { front = sgn * dot(ray.d, nw) < 0.0f; sgn = front ? sgn : -sgn; }
+      V3<float> p = ray.at(closest);
+      if (!(f.flags & (OBJ_ROTATE_Y | OBJ_TRANSLATE))) {  // an untransformed side: the point lies on its plane exactly
+        p.x = axis == 0 ? f.k : p.x; p.y = axis == 1 ? f.k : p.y; p.z = axis == 2 ? f.k : p.z;
+      }
+      rec.t = closest; rec.p = p; rec.n = sgn * nw; rec.front = front;
+      rec.mat = s.material; rec.obj = s.obj_id; rec.sub = s.sub_id;
+      rec.side = best_side; rec.leaf = best_leaf; rec.uv_lazy = 0;
+      RT_STAMP_IN(media, 5);
+      return true;
+    }
+  }
   finalize_hit<float, C>(sv, ray, closest, best_leaf, best_side, rec);
   RT_STAMP_IN(media, 5);
   return true;

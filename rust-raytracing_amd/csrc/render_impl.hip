@@ -82,8 +82,34 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
   lay.n_flat = (uint32_t)others.size();
   lay.frect_off = off; off = align16(off + (uint32_t)(kFlatMaxLeaves * sizeof(FlatRect)));
   for (int k = 0; k < 3; ++k) lay.n_frect[k] = (uint32_t)frects[k].size();
+  lay.faces_off = off;
+  if (lay.flat_mode) off = align16(off + (uint32_t)(6u * lay.n_objects * sizeof(FlatFace)));
   lay.total_bytes = off;
   std::vector<uint8_t> blob(off, 0);
+  if (lay.flat_mode) {
+    FlatFace* F = reinterpret_cast<FlatFace*>(blob.data() + lay.faces_off);
+    for (int i = 0; i < s.n_objects; ++i) {
+      const rt_object& o = s.objects[i];
+      if (o.flags & RT_OBJ_SUB_BVH) continue;
+      const rt_shape& sh = s.shapes[o.geom];
+      const bool box = sh.tag == RT_SHAPE_BOX;
+      if (!box && sh.tag != RT_SHAPE_RECT_XY && sh.tag != RT_SHAPE_RECT_XZ && sh.tag != RT_SHAPE_RECT_YZ) continue;
+      const bool rot = (o.flags & RT_OBJ_ROTATE_Y) != 0;
+      const float cs = rot ? (float)o.cos_theta : 1.0f, sn = rot ? (float)o.sin_theta : 0.0f;
+      for (int side = 0; side < (box ? 6 : 1); ++side) {
+        // box sides: 0 z=hi, 1 z=lo, 2 y=hi, 3 y=lo, 4 x=hi, 5 x=lo (the reference's list order, src/box_struct.rs:22-71)
+        const int axis = box ? (side < 2 ? 2 : side < 4 ? 1 : 0) : (sh.tag == RT_SHAPE_RECT_XY ? 2 : sh.tag == RT_SHAPE_RECT_XZ ? 1 : 0);
+        static const int box_k[6] = {5, 2, 4, 1, 3, 0};
+        FlatFace& f = F[6 * i + side];
+        f.n[0] = axis == 0 ? cs : axis == 2 ? sn : 0.0f;   // RotateY of the axis vector (src/hittable.rs:229-239)
+        f.n[1] = axis == 1 ? 1.0f : 0.0f;
+        f.n[2] = axis == 0 ? -sn : axis == 2 ? cs : 0.0f;
+        f.flags = (o.flags & 15u) | ((uint32_t)axis << 4);
+        f.cos_theta = cs; f.sin_theta = sn;
+        f.k = (float)(box ? sh.p[box_k[side]] : sh.p[4]);
+      }
+    }
+  }
   if (!others.empty()) memcpy(blob.data() + lay.flat_off, others.data(), others.size() * sizeof(uint32_t));
   {
     FlatRect* fr = reinterpret_cast<FlatRect*>(blob.data() + lay.frect_off);
