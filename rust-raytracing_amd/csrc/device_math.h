@@ -114,15 +114,31 @@ struct Stream {
       : k0(pixel), k1(sample), c1(bounce | (stage << 16)), c2((uint32_t)seed), c3((uint32_t)(seed >> 32)) {}
   RT_DEV void hi(uint32_t block, uint32_t h[4]) const { philox4x32(block, c1, c2, c3, k0, k1, h[0], h[1], h[2], h[3]); }
   RT_DEV void lo(uint32_t block, uint32_t l[4]) const { philox4x32(block, c1 | (1u << 20), c2, c3, k0, k1, l[0], l[1], l[2], l[3]); }
+  // where a rejection loop starts reading candidate blocks, and whether it has to stop before block b (never, for a plain stream)
+  RT_DEV uint32_t first_block() const { return 0u; }
+  RT_DEV bool out_of_turn(uint32_t) const { return false; }
 };
 // A stream whose H block 0 is already computed.  The path kernels evaluate that block once per turn for all lanes - a scatter
 // stream in the lanes that continue a path, a camera stream in the lanes that start one - so both uses share one pass of Philox.
+//
+// A rejection loop on such a stream looks at `per_turn` blocks and then gives up for this turn, leaving in `resume` the block
+// to go on from; the kernel keeps the lane's hit and calls again next turn with b0 = resume.  A wave repeats the loop until its
+// unluckiest lane is done (five blocks on average for a full wave, when a lane needs 1.3), and blocks are addressed, so putting
+// off the few lanes that are still looking after two blocks changes no result and saves most of those passes.
 struct PrimedStream : Stream {
+  uint32_t b0, per_turn;
   uint32_t h0[4];
-  RT_DEV explicit PrimedStream(const Stream& s) : Stream(s) { Stream::hi(0u, h0); }
+  mutable uint32_t resume = 0u;  // != 0: the draw was not finished, continue at this block
+  RT_DEV PrimedStream(const Stream& s, uint32_t first, uint32_t blocks_per_turn) : Stream(s), b0(first), per_turn(blocks_per_turn) { Stream::hi(b0, h0); }
   RT_DEV void hi(uint32_t block, uint32_t h[4]) const {
-    if (block == 0u) { h[0] = h0[0]; h[1] = h0[1]; h[2] = h0[2]; h[3] = h0[3]; }
+    if (block == b0) { h[0] = h0[0]; h[1] = h0[1]; h[2] = h0[2]; h[3] = h0[3]; }
     else Stream::hi(block, h);
+  }
+  RT_DEV uint32_t first_block() const { return b0; }
+  RT_DEV bool out_of_turn(uint32_t b) const {
+    if (b < b0 + per_turn) return false;
+    resume = b;
+    return true;
   }
 };
 
@@ -192,7 +208,8 @@ template <class R> RT_DEV V3<R> point_of(uint32_t w0, uint32_t w1, uint32_t l0, 
   return V3<R>(coord_of(xi, l0 >> 1, (R)0), coord_of(yi, l1 >> 1, (R)0), coord_of(zi, l2 >> 1, (R)0));
 }
 template <class S> RT_DEV V3<float> random_in_unit_sphere(const S& s, float) {
-  for (uint32_t b = 0;; ++b) {
+  for (uint32_t b = s.first_block();; ++b) {
+    if (s.out_of_turn(b)) return V3<float>(0.0f, 0.0f, 1.0f);  // not a draw: the caller sees s.resume and calls again
     uint32_t h[4];
     s.hi(b, h);
     V3<float> p = point_of<float>(h[0], h[1], 0u, 0u, 0u);
@@ -207,12 +224,15 @@ template <class S> RT_DEV V3<float> random_in_unit_sphere(const S& s, float) {
 // Double build: the high fields alone decide all but a sliver of candidates (the low fields move a coordinate by less than
 // 2^-20, the squared length by less than 5.8e-6), so the low block is fetched once, for the candidate that passes that test.
 template <class S> RT_DEV V3<double> random_in_unit_sphere(const S& s, double) {
-  uint32_t c = 0;
+  uint32_t c = 2u * s.first_block();
   uint32_t h[4] = {0u, 0u, 0u, 0u};
   for (;;) {
     uint32_t w0, w1;
     for (;; ++c) {
-      if ((c & 1u) == 0u) s.hi(c >> 1, h);
+      if ((c & 1u) == 0u) {
+        if (s.out_of_turn(c >> 1)) return V3<double>(0.0, 0.0, 1.0);  // not a draw: the caller sees s.resume and calls again
+        s.hi(c >> 1, h);
+      }
       w0 = (c & 1u) ? h[2] : h[0];
       w1 = (c & 1u) ? h[3] : h[1];
       if (length_squared(point_of<double>(w0, w1, 0u, 0u, 0u)) < 1.0 + 6e-6) break;

@@ -234,6 +234,12 @@ __global__ __launch_bounds__(256) void k_bounce_fused(DeviceScene<R> sc, FramePa
 // queues: nothing is written to memory between bounces except the radiance sums.  A path's random streams are keyed by
 // (pixel, sample, bounce), so its result does not depend on which lane or iteration it ran in.
 constexpr uint32_t kPathGrab = 2048;
+// Blocks of candidates a scatter draw may look at before it is put off to the lane's next visit to the shading code: the
+// persistent kernel comes back every turn, the stepwise kernel only at its next restart.
+#ifndef RT_BLOCKS_PER_RESTART
+#define RT_BLOCKS_PER_RESTART 3
+#endif
+constexpr uint32_t kBlocksPerTurn = 2, kBlocksPerRestart = RT_BLOCKS_PER_RESTART;
 #ifndef RT_NESTED_WAVES
 #define RT_NESTED_WAVES 4
 #endif
@@ -296,6 +302,7 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : 1) void k
   PathFeeder<R> feeder;
   bool active = false;   // the lane holds a path
   bool hit = false;      // ... whose last ray hit something: `rec` waits to be shaded
+  uint32_t resume = 0;   // != 0: the scatter draw of that hit is unfinished and continues at this block of its stream
   uint32_t bounce = 0;
   unsigned long long n_rays = 0;
   PathState<R> st;
@@ -325,24 +332,27 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : 1) void k
     feeder.template refill<false>(sc, fp, total_paths, path_cursor, st, bounce, active);
     RT_STAMP(0);
     if (__ballot(active) == 0ull) break;
-    const PrimedStream rng(Stream(fp.seed, st.pixel, st.sample, bounce, to_scatter ? STAGE_SCATTER : STAGE_CAMERA));
+    const PrimedStream rng(Stream(fp.seed, st.pixel, st.sample, bounce, to_scatter ? STAGE_SCATTER : STAGE_CAMERA), to_scatter ? resume : 0u, kBlocksPerTurn);
     if (to_scatter) {
       V3<R> emitted, attenuation;
       Ray<R> scattered;
       const bool alive = shade_hit<R, C>(sv, st.ray, rec, rng, emitted, attenuation, scattered);
-      add_radiance(accum, st.pixel, st.thr * emitted);
-      ++bounce;
-      st.thr = st.thr * attenuation;
-      st.ray = scattered;
-      st.org = Origin(rec.leaf, rec.side);
-      active = alive;
+      resume = rng.resume;
+      if (resume == 0u) {  // otherwise the draw goes on next turn, from block `resume`, and the lane keeps its hit until then
+        ++bounce;
+        st.thr = st.thr * attenuation;
+        st.ray = scattered;
+        st.org = Origin(rec.leaf, rec.side);
+        active = alive;
+      }
     } else if (active) {
       st.ray = primary_ray<R>(sc.camera, fp.width, fp.height, st.pixel, rng);
     }
     RT_STAMP(2);
-    n_rays += (unsigned long long)__popcll(__ballot(active));
-    hit = false;
-    if (active) {
+    const bool go = active && resume == 0u;
+    n_rays += (unsigned long long)__popcll(__ballot(go));
+    if (go) {
+      hit = false;
       rec = Rec<R>();
       Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
       RT_STAMP_ATTACH(media);
@@ -379,6 +389,7 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : RT_STEP_W
   const uint32_t lane = threadIdx.x & 63u;
   PathFeeder<R> feeder;
   bool active = false;  // the lane holds a path
+  uint32_t resume = 0;  // != 0: the scatter draw of the lane's hit is unfinished and continues at this block of its stream
   uint32_t bounce = 0;
   unsigned long long n_rays = 0;
   PathState<R> st;
@@ -411,22 +422,24 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : RT_STEP_W
       }
       feeder.template refill<false>(sc, fp, total_paths, path_cursor, st, bounce, active);
       if (i < 0 && active) {  // one Philox pass: scatter draw of the continuing lanes, pixel jitter of the new ones
-        const PrimedStream rng(Stream(fp.seed, st.pixel, st.sample, bounce, to_scatter ? STAGE_SCATTER : STAGE_CAMERA));
+        const PrimedStream rng(Stream(fp.seed, st.pixel, st.sample, bounce, to_scatter ? STAGE_SCATTER : STAGE_CAMERA), to_scatter ? resume : 0u, kBlocksPerRestart);
         if (to_scatter) {
           V3<R> emitted, attenuation;
           Ray<R> scattered;
           const bool alive = shade_hit<R, C>(sv, st.ray, rec, rng, emitted, attenuation, scattered);
-          add_radiance(accum, st.pixel, st.thr * emitted);
-          ++bounce;
-          st.thr = st.thr * attenuation;
-          st.ray = scattered;
-          st.org = Origin(rec.leaf, rec.side);
-          active = alive;
+          resume = rng.resume;
+          if (resume == 0u) {  // otherwise the draw goes on at the next restart, and the lane keeps its hit until then
+            ++bounce;
+            st.thr = st.thr * attenuation;
+            st.ray = scattered;
+            st.org = Origin(rec.leaf, rec.side);
+            active = alive;
+          }
         } else {
           st.ray = primary_ray<R>(sc.camera, fp.width, fp.height, st.pixel, rng);
         }
       }
-      const bool start = i < 0 && active;
+      const bool start = i < 0 && active && resume == 0u;
       n_rays += (unsigned long long)__popcll(__ballot(start));
       if (start) {
         box = LaneBoxTest<R>(st.ray);
@@ -436,7 +449,7 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : RT_STEP_W
         any = false;
         rec = Rec<R>();  // a fresh HitRecord per world.hit call (src/render.rs:157)
       }
-      if (__ballot(i >= 0) == 0ull) break;  // no walk in progress and no path left to start
+      if (__ballot(i >= 0 || resume != 0u) == 0ull) break;  // no walk in progress, no draw unfinished, no path left to start
     }
 #pragma unroll 1
     for (int turn = 0; turn < kTurnsPerCheck; ++turn) {
