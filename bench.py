@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--pipeline", choices=["auto", "fused", "sorted", "persistent"], default="auto")
     ap.add_argument("--samples-per-pass", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the bounded CPU sample")
+    ap.add_argument("--cpu-spp", type=int, default=96, help="samples per pixel of the bounded CPU sample")
     ap.add_argument("--save", default="", help="rank 0 writes the last image here (.png/.ppm)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the multi-rank path on a box with fewer GPUs than ranks (sums travel through host memory)")
