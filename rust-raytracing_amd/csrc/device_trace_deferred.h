@@ -343,7 +343,7 @@ RT_DEV bool box_slab_span(const DShape<float>& s, const Ray<float>& ray, const R
 
 // Single precision, scenes of a few leaves: every leaf is tested with the same shrinking t_max - plain rectangles first,
 // grouped by axis, then the other leaves in the order the tree would visit them (among exactly coincident surfaces the last
-// one tested is reported, so at shared edges the order shows); only the root box is kept as an early out.  A box test can only skip leaves the ray does not hit (up to
+// one tested is reported, so at shared edges the order shows).  A box test can only skip leaves the ray does not hit (up to
 // rounding at grazing incidence, which the single-precision tolerance covers), and with incoherent rays every wave visits
 // every entry anyway, so the inner box tests and the per-lane position in the tree are pure overhead here.
 template <class C>
@@ -352,10 +352,11 @@ RT_DEV bool traverse_flat(const SceneView<float, C>& sv, int start, const Ray<fl
   const RayInv<float> ri(ray.d);
   float closest = t_max;
   int best_leaf = -1, best_side = -1;
-  const DLink<float> root = sv.link_uniform(start);
-  const bool inside = (root.hit & LEAF_FLAG) ? true : aabb_hit(root, ray, ri.inv, t_min, closest);
+  // No box test at all, not even the root's: a ray that starts on a surface starts inside the root box, and camera rays that miss
+  // it share their wave with lanes at other bounces, so the early out would never be taken by a whole wave.
+  (void)start;
   RT_STAMP_IN(media, 3);
-  if (inside) {
+  {
     const int org_leaf = org.leaf(), org_side = org.side();
     // plain rectangles, one list per constant axis: one record fetch and a dozen vector instructions each
     const FlatRect* fr = sv.frect;
