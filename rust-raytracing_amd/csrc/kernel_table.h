@@ -19,7 +19,8 @@ template <class R> struct KernelTable {
   void (*shade)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, PathQueue<R> in, HitQueue<R> hits,
                 PathQueue<R> out, uint32_t* counters, uint32_t* cursors, const uint32_t* class_counters, const uint32_t* class_index, uint32_t capacity,
                 R* accum, uint32_t bounce);
-  void (*first_hit)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const RayIO* rays, uint32_t n, HitIO* hits, uint64_t seed);
+  void (*first_hit)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const RayIO* rays, uint32_t n, HitIO* hits, uint64_t seed,
+                    bool as_rendered);
   void (*sample_radiance)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, uint32_t W, uint32_t H, uint32_t max_depth,
                           const uint32_t* pixel, const uint32_t* sample, uint32_t n, uint64_t seed, double* out, double* path_out, uint32_t max_vertices);
 };
@@ -74,8 +75,10 @@ template <class R, class C> KernelTable<R> make_table() {
     hipLaunchKernelGGL((k_shade<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, in, hits, out, counters, cursors, class_counters, class_index,
                        capacity, accum, bounce);
   };
-  t.first_hit = [](uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const RayIO* rays, uint32_t n, HitIO* hits, uint64_t seed) {
-    hipLaunchKernelGGL((k_first_hit<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, rays, n, hits, seed);
+  t.first_hit = [](uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const RayIO* rays, uint32_t n, HitIO* hits, uint64_t seed,
+                   bool as_rendered) {
+    if (as_rendered) hipLaunchKernelGGL((k_first_hit<R, C, true>), dim3(grid), dim3(kBlockThreads), lds, st, sc, rays, n, hits, seed);
+    else hipLaunchKernelGGL((k_first_hit<R, C, false>), dim3(grid), dim3(kBlockThreads), lds, st, sc, rays, n, hits, seed);
   };
   t.sample_radiance = [](uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, uint32_t W, uint32_t H, uint32_t max_depth,
                          const uint32_t* pixel, const uint32_t* sample, uint32_t n, uint64_t seed, double* out, double* path_out,

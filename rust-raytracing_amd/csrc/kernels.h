@@ -606,10 +606,12 @@ struct HitIO {  // = rt_hit
   double t, p[3], n[3], u, v;
 };
 
-template <class R, class C>
+// AS_RENDERED = false: the inspection entry reports (u, v) whatever the scene's textures read.  true: the kernel configuration the
+// render kernels run, so that their record building is what gets inspected ((u, v) then stay 0 in scenes that never read them).
+template <class R, class C, bool AS_RENDERED>
 __global__ __launch_bounds__(256) void k_first_hit(DeviceScene<R> sc, const RayIO* rays, uint32_t n, HitIO* hits, uint64_t seed) {
   extern __shared__ __align__(16) uint8_t lds[];
-  using CU = Cfg<C::F | F_UV, C::walk>;  // the inspection entry always reports (u, v)
+  using CU = Cfg<AS_RENDERED ? C::F : (C::F | F_UV), C::walk>;
   const SceneView<R, CU> sv = make_view<R, CU>(sc, lds);
   uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {

@@ -383,7 +383,7 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
   return RT_OK;
 }
 
-template <class R> int trace_batch_impl(rt_context* c, const rt_ray* rays, size_t n, rt_hit* hits, uint64_t seed) {
+template <class R> int trace_batch_impl(rt_context* c, const rt_ray* rays, size_t n, rt_hit* hits, uint64_t seed, bool as_rendered) {
   SceneImage<R>& im = image_of<R>(c);
   RayIO* d_rays = nullptr;
   HitIO* d_hits = nullptr;
@@ -394,7 +394,7 @@ template <class R> int trace_batch_impl(rt_context* c, const rt_ray* rays, size_
   do {
     if (hipMemcpyAsync(d_rays, rays, n * sizeof(RayIO), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(RT_E_HIP, "H2D rays failed"); break; }
     uint32_t grid = grid_for(c, n, 8);
-    im.table.first_hit(grid, im.lds_bytes, c->stream, im.dev, d_rays, (uint32_t)n, d_hits, seed);
+    im.table.first_hit(grid, im.lds_bytes, c->stream, im.dev, d_rays, (uint32_t)n, d_hits, seed, as_rendered);
     if (hipGetLastError() != hipSuccess) { rc = fail(RT_E_HIP, "k_first_hit launch failed"); break; }
     if (hipMemcpyAsync(hits, d_hits, n * sizeof(HitIO), hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail(RT_E_HIP, "D2H hits failed"); break; }
     if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(RT_E_HIP, "stream sync failed after k_first_hit"); break; }
@@ -453,7 +453,7 @@ template <class R> int resolve_impl(rt_context* c, const void* accum_dev, size_t
 #define RTI_INSTANTIATE(R)                                                                                                                   \
   template int build_image<R>(rt_context*, const rt_scene_desc&, const std::vector<TmpLink>&, int, const std::vector<int>&, int, SceneImage<R>&); \
   template int render_accum_impl<R>(rt_context*, const rt_render_params&, void*, rt_stats*);                                                \
-  template int trace_batch_impl<R>(rt_context*, const rt_ray*, size_t, rt_hit*, uint64_t);                                                  \
+  template int trace_batch_impl<R>(rt_context*, const rt_ray*, size_t, rt_hit*, uint64_t, bool);                                                  \
   template int pairs_kernel_impl<R>(rt_context*, int, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint32_t*, size_t, uint64_t, void*, \
                                     size_t);                                                                                               \
   template int resolve_impl<R>(rt_context*, const void*, size_t, uint32_t, uint8_t*);

@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(BUILD_DIR, "librtamd.so")
 HOST_LIB_PATH = os.path.join(BUILD_DIR, "librtamd_host.so")
 
 F32, F64 = 0, 1
+TRACE_AS_RENDERED = 0x100  # rt_trace_batch: records built by the render kernels' own configuration
 PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_SORTED, PIPELINE_PERSISTENT = 0, 1, 2, 3
 
 SCENES = {
@@ -274,10 +275,10 @@ class Context:
         _check(self.L.rt_read_accum(self.h, C.c_void_p(accum_dev_ptr) if accum_dev_ptr else None, width, height, precision, _p(out)))
         return out
 
-    def trace_batch(self, rays, precision=F64, seed=0):
+    def trace_batch(self, rays, precision=F64, seed=0, as_rendered=False):
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
         hits = np.zeros(rays.size, dtype=HIT_DTYPE)
-        _check(self.L.rt_trace_batch(self.h, _p(rays), rays.size, _p(hits), precision, seed))
+        _check(self.L.rt_trace_batch(self.h, _p(rays), rays.size, _p(hits), precision | (TRACE_AS_RENDERED if as_rendered else 0), seed))
         return hits
 
     def camera_rays(self, pixel, sample, seed=0, precision=F64, width=0, height=0):
