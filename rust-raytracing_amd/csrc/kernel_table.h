@@ -46,7 +46,7 @@ template <class R, class C> KernelTable<R> make_table() {
     if constexpr (!use_stepwise<C>())
       hipLaunchKernelGGL((k_paths_persistent<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
     else
-      hipLaunchKernelGGL((k_paths_stepwise<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
+      hipLaunchKernelGGL((k_paths_stepwise<R, C>), dim3(grid), dim3(kStepThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
   };
   t.resident_blocks_per_cu = [](int kernel, uint32_t lds) {
     int n = 0;
@@ -57,7 +57,7 @@ template <class R, class C> KernelTable<R> make_table() {
       case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade<R, C>, (int)kBlockThreads, lds); break;
       case 3:
         if constexpr (!use_stepwise<C>()) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths_persistent<R, C>, (int)kBlockThreads, lds);
-        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths_stepwise<R, C>, (int)kBlockThreads, lds);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths_stepwise<R, C>, (int)kStepThreads, lds);
         break;
       default: break;
     }
