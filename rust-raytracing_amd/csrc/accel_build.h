@@ -39,8 +39,11 @@ class FastTreeBuilder {
 
   // `ref` are the links of the reference trees before reordering, `ref_root` / `ref_sub_root` their roots.
   // Fills `links` (top-level tree first, then the nested ones), `root` and `sub_root`.
-  void build(const std::vector<TmpLink>& ref, int ref_root, const std::vector<int>& ref_sub_root, std::vector<TmpLink>& links, int& root,
-             std::vector<int>& sub_root) {
+  // `dissolved[o]` != 0: the nested tree held by object o is not built; its objects - which the caller has given o's own
+  // Translate / RotateY - join the main tree as ordinary leaves.  Translate(RotateY(tree of shapes)) reports the closest of
+  // Translate(RotateY(shape)) over its shapes, record for record (both wrappers keep t), so only tie order can differ.
+  void build(const std::vector<TmpLink>& ref, int ref_root, const std::vector<int>& ref_sub_root, const std::vector<char>& dissolved,
+             std::vector<TmpLink>& links, int& root, std::vector<int>& sub_root) {
     links.clear();
     sub_root.assign((size_t)s_.n_objects, LINK_END);
     nested_box_.assign((size_t)s_.n_objects, Box3d{});
@@ -48,7 +51,7 @@ class FastTreeBuilder {
     std::vector<std::vector<TmpLink>> nested_links;
     std::vector<int> nested_owner;
     for (int o = 0; o < s_.n_objects; ++o) {
-      if (!(s_.objects[o].flags & RT_OBJ_SUB_BVH)) continue;
+      if (!(s_.objects[o].flags & RT_OBJ_SUB_BVH) || dissolved[(size_t)o]) continue;
       std::vector<int> objs = leaves_in_visiting_order(ref, ref_sub_root[(size_t)o], s_.n_objects);
       nested_links.emplace_back();
       nested_owner.push_back(o);
@@ -56,7 +59,11 @@ class FastTreeBuilder {
       emit_tree(objs, (int)nested_links.size(), nested_links.back(), rb);
       nested_box_[(size_t)o] = rb;
     }
-    std::vector<int> top = leaves_in_visiting_order(ref, ref_root, s_.n_objects);
+    std::vector<int> top;
+    for (int o : leaves_in_visiting_order(ref, ref_root, s_.n_objects)) {
+      if (!dissolved[(size_t)o]) { top.push_back(o); continue; }
+      for (int child : leaves_in_visiting_order(ref, ref_sub_root[(size_t)o], s_.n_objects)) top.push_back(child);
+    }
     Box3d unused;
     emit_tree(top, 0, links, unused);
     root = 0;

@@ -148,11 +148,15 @@ using CfgSpheres = Cfg<P_SPHERES, WALK_UNIFORM>;
 constexpr uint32_t P_BALLS = F_SPHERE | F_MOVING | F_CHECKER | F_METAL | F_DIELECTRIC | F_GRADIENT;  // random, mega-spheres
 using CfgAllLds = Cfg<F_ALL, WALK_LANE_LDS_ALL>;
 using CfgAllTop = Cfg<F_ALL, WALK_LANE_LDS_TOP>;
+// every feature except nested trees: single-precision images whose nested trees were dissolved into the main tree at upload
+using CfgFlatAllLds = Cfg<F_ALL & ~F_NESTED, WALK_LANE_LDS_ALL>;
+using CfgFlatAllTop = Cfg<F_ALL & ~F_NESTED, WALK_LANE_LDS_TOP>;
 using CfgBallsLds = Cfg<P_BALLS, WALK_LANE_LDS_ALL>;
 using CfgBallsTop = Cfg<P_BALLS, WALK_LANE_LDS_TOP>;
 enum {
   PRESET_BOXES = 0, PRESET_SMOKE = 1, PRESET_SPHERES = 2, PRESET_ALL_LDS = 3, PRESET_ALL_TOP = 4, PRESET_BALLS_LDS = 5, PRESET_BALLS_TOP = 6,
-  PRESET_COUNT = 7
+  PRESET_FLATALL_LDS = 7, PRESET_FLATALL_TOP = 8,  // single precision only
+  PRESET_COUNT = 9
 };
 
 // Read-only record at a wave-uniform address in global memory that no kernel writes (the scene blob): loaded through

@@ -372,6 +372,10 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : 1) void k
 #ifndef RT_STEP_WAVES
 #define RT_STEP_WAVES 1
 #endif
+// The stepwise kernel with every feature compiled in wants 195 registers (two waves per SIMD); this asks for more waves.
+#ifndef RT_STEP_WAVES_FULL
+#define RT_STEP_WAVES_FULL 4
+#endif
 #ifndef RT_STEP_THREADS
 #define RT_STEP_THREADS 256
 #endif
@@ -386,7 +390,7 @@ constexpr int kBoxStepsPerTurn = RT_BOX_STEPS;
 constexpr int kTurnsPerCheck = RT_TURNS;
 
 template <class R, class C>
-__global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES : RT_STEP_WAVES) void k_paths_stepwise(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
+__global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES : (C::has(F_NOISE) ? RT_STEP_WAVES_FULL : RT_STEP_WAVES)) void k_paths_stepwise(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
                                                         unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
   extern __shared__ __align__(16) uint8_t lds[];
   const SceneView<R, C> sv = make_view<R, C>(sc, lds);

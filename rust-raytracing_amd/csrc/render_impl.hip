@@ -13,8 +13,11 @@ template <class R> KernelTable<R> table_for(int preset) {
     case PRESET_ALL_LDS: return kernel_table<R, PRESET_ALL_LDS>();
     case PRESET_BALLS_LDS: return kernel_table<R, PRESET_BALLS_LDS>();
     case PRESET_BALLS_TOP: return kernel_table<R, PRESET_BALLS_TOP>();
-    default: return kernel_table<R, PRESET_ALL_TOP>();
+    case PRESET_FLATALL_LDS: if constexpr (sizeof(R) == sizeof(float)) return kernel_table<float, PRESET_FLATALL_LDS>(); else break;
+    case PRESET_FLATALL_TOP: if constexpr (sizeof(R) == sizeof(float)) return kernel_table<float, PRESET_FLATALL_TOP>(); else break;
+    default: break;
   }
+  return kernel_table<R, PRESET_ALL_TOP>();
 }
 
 static_assert(sizeof(RayIO) == sizeof(rt_ray), "rt_ray layout");
@@ -164,6 +167,7 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
   HIP_TRY(hipMemcpy(im.d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
   if (preset == PRESET_ALL_LDS && lay.total_bytes > kLdsAllMax) preset = PRESET_ALL_TOP;  // the f64 image is larger than the f32 one
   if (preset == PRESET_BALLS_LDS && lay.total_bytes > kLdsAllMax) preset = PRESET_BALLS_TOP;
+  if (preset == PRESET_FLATALL_LDS && lay.total_bytes > kLdsAllMax) preset = PRESET_FLATALL_TOP;
   im.preset = preset;
   im.table = table_for<R>(preset);
   DeviceScene<R>& d = im.dev;
@@ -172,7 +176,7 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
   d.images = c->d_images;
   d.n_images = s.n_images;
   d.root_link = root_link;
-  d.lds_links = (preset == PRESET_ALL_TOP || preset == PRESET_BALLS_TOP) ? std::min<uint32_t>(lay.n_links, kLdsTopMax / (uint32_t)sizeof(DLink<R>)) : 0u;
+  d.lds_links = (preset == PRESET_ALL_TOP || preset == PRESET_BALLS_TOP || preset == PRESET_FLATALL_TOP) ? std::min<uint32_t>(lay.n_links, kLdsTopMax / (uint32_t)sizeof(DLink<R>)) : 0u;
   im.lds_bytes = im.table.lds_bytes(lay, d.lds_links);
   auto v3 = [](const double* p) { return V3<R>((R)p[0], (R)p[1], (R)p[2]); };
   d.camera.origin = v3(s.camera.origin); d.camera.lower_left_corner = v3(s.camera.lower_left_corner);

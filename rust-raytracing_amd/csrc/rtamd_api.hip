@@ -283,10 +283,62 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   std::vector<TmpLink> fast_links;
   int fast_root = LINK_END;
   std::vector<int> fast_sub_root;
+  // There, a nested tree whose holder only translates / rotates it and whose objects are bare shapes is dissolved: the objects
+  // take the holder's wrappers and become leaves of the main tree.  A scene left without nested trees runs the kernels that carry
+  // no nested-walk code (half the registers).  RTAMD_KEEP_NESTED=1 turns this off.
   const bool own_tree = !uniform && !std::getenv("RTAMD_REFERENCE_TREE");
+  std::vector<rt_object> objects32(s->objects, s->objects + s->n_objects);
+  std::vector<rt_shape> shapes32(s->shapes, s->shapes + s->n_shapes);
+  std::vector<char> dissolved((size_t)s->n_objects, 0);
+  int preset32 = preset;
   if (own_tree) {
-    FastTreeBuilder ftb(*s);
-    ftb.build(lb.links, root, sub_root, fast_links, fast_root, fast_sub_root);
+    bool nested_left = false;
+    for (int i = 0; i < s->n_objects; ++i) {
+      const rt_object& holder = s->objects[i];
+      if (!(holder.flags & RT_OBJ_SUB_BVH)) continue;
+      std::vector<int> children;
+      for (int k = sub_root[(size_t)i]; k >= 0;) {
+        const TmpLink& l = lb.links[(size_t)k];
+        if (l.hit & LEAF_FLAG) { children.push_back((int)(l.hit & LEAF_INDEX_MASK)); k = l.miss; }
+        else k = (int)l.hit;
+      }
+      bool bare = !(holder.flags & RT_OBJ_MEDIUM) && !std::getenv("RTAMD_KEEP_NESTED");
+      for (int ch : children) bare = bare && s->objects[ch].flags == 0u;
+      if (!bare) { nested_left = true; continue; }
+      dissolved[(size_t)i] = 1;
+      for (int ch : children) {
+        rt_object& o = objects32[(size_t)ch];
+        // A sphere under RotateY / Translate is the sphere around the moved centre: same t, same point, same normal.  Only the
+        // front_face flag can differ, at grazing incidence, through RotateY's mixed-frame set_face_normal (src/hittable.rs:236-239)
+        // - it is read by Dielectric alone - and (u, v) turn with the sphere, so those materials keep the wrappers.
+        const rt_shape& sh = s->shapes[o.geom];
+        const rt_material& m = s->materials[sh.material];
+        const bool uv_free = m.texture < 0 || m.texture >= s->n_textures || s->textures[m.texture].tag != RT_TEX_IMAGE;
+        if (sh.tag == RT_SHAPE_SPHERE && m.tag != RT_MAT_DIELECTRIC && uv_free) {
+          shapes32.push_back(sh);
+          rt_shape& moved = shapes32.back();
+          const bool rot = (holder.flags & RT_OBJ_ROTATE_Y) != 0, tr = (holder.flags & RT_OBJ_TRANSLATE) != 0;
+          const double cs = rot ? holder.cos_theta : 1.0, sn = rot ? holder.sin_theta : 0.0;
+          moved.p[0] = cs * sh.p[0] + sn * sh.p[2] + (tr ? holder.offset[0] : 0.0);   // src/hittable.rs:229-232, 146
+          moved.p[1] = sh.p[1] + (tr ? holder.offset[1] : 0.0);
+          moved.p[2] = -sn * sh.p[0] + cs * sh.p[2] + (tr ? holder.offset[2] : 0.0);
+          o.geom = (int32_t)shapes32.size() - 1;
+          continue;
+        }
+        o.flags = holder.flags & (RT_OBJ_TRANSLATE | RT_OBJ_ROTATE_Y);
+        for (int k = 0; k < 3; ++k) o.offset[k] = holder.offset[k];
+        o.sin_theta = holder.sin_theta; o.cos_theta = holder.cos_theta;
+      }
+    }
+    if (has_nested && !nested_left && preset == PRESET_ALL_LDS) preset32 = PRESET_FLATALL_LDS;  // build_image demotes to _TOP when too large
+  }
+  rt_scene_desc scene32 = *s;
+  scene32.objects = objects32.data();
+  scene32.shapes = shapes32.data();
+  scene32.n_shapes = (int32_t)shapes32.size();
+  if (own_tree) {
+    FastTreeBuilder ftb(scene32);
+    ftb.build(lb.links, root, sub_root, dissolved, fast_links, fast_root, fast_sub_root);
     fast_links = reorder(fast_links, fast_root, fast_sub_root);
   }
   std::vector<TmpLink> links = reorder(lb.links, root, sub_root);
@@ -306,7 +358,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     HIP_TRY(hipMalloc((void**)&c->d_images, sizeof(DImage) * host_images.size()));
     HIP_TRY(hipMemcpy(c->d_images, host_images.data(), sizeof(DImage) * host_images.size(), hipMemcpyHostToDevice));
   }
-  rc = own_tree ? build_image<float>(c, *s, fast_links, fast_root, fast_sub_root, preset, c->sf)
+  rc = own_tree ? build_image<float>(c, scene32, fast_links, fast_root, fast_sub_root, preset32, c->sf)
                 : build_image<float>(c, *s, links, root, sub_root, preset, c->sf);
   if (rc == RT_OK) rc = build_image<double>(c, *s, links, root, sub_root, preset, c->sd);
   if (rc != RT_OK) { free_scene(c); return rc; }
