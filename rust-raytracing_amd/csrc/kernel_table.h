@@ -43,10 +43,15 @@ template <class R, class C> KernelTable<R> make_table() {
   };
   t.paths_persistent = [](uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, unsigned long long total_paths,
                           unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
-    if constexpr (!use_stepwise<C>())
-      hipLaunchKernelGGL((k_paths_persistent<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
-    else
-      hipLaunchKernelGGL((k_paths_stepwise<R, C>), dim3(grid), dim3(kStepThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
+    const bool fixed = fp.path_grab == kPathGrab;
+    if constexpr (!use_stepwise<C>()) {
+      if (fixed) hipLaunchKernelGGL((k_paths_persistent<R, C, true>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
+      else hipLaunchKernelGGL((k_paths_persistent<R, C, false>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
+    }
+    else {
+      if (fixed) hipLaunchKernelGGL((k_paths_stepwise<R, C, true>), dim3(grid), dim3(kStepThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
+      else hipLaunchKernelGGL((k_paths_stepwise<R, C, false>), dim3(grid), dim3(kStepThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
+    }
   };
   t.resident_blocks_per_cu = [](int kernel, uint32_t lds) {
     int n = 0;
@@ -56,8 +61,8 @@ template <class R, class C> KernelTable<R> make_table() {
       case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<R, C>, (int)kBlockThreads, lds); break;
       case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade<R, C>, (int)kBlockThreads, lds); break;
       case 3:
-        if constexpr (!use_stepwise<C>()) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths_persistent<R, C>, (int)kBlockThreads, lds);
-        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths_stepwise<R, C>, (int)kStepThreads, lds);
+        if constexpr (!use_stepwise<C>()) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths_persistent<R, C, true>, (int)kBlockThreads, lds);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths_stepwise<R, C, true>, (int)kStepThreads, lds);
         break;
       default: break;
     }

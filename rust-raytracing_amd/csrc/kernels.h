@@ -115,6 +115,9 @@ struct FrameParams {
   // counter of its own (one shared counter saturates at under 10^8 returning atomics per second, far below the rate at
   // which waves finish), and because workgroups b and b + 8 share an XCD a segment's rays stay in one XCD's L2.
   uint32_t n_seg, seg_cap;
+  // Paths a wave of the path kernels takes from the global cursor at a time: kPathGrab on large frames, fewer when the frame has
+  // only a few grabs per wave to hand out (the last grabs decide how evenly the frame ends).
+  uint32_t path_grab;
 };
 
 struct Segment {
@@ -253,19 +256,21 @@ template <class R> struct PathFeeder {
 
   // Gives every lane with `!active` a new path while there are any; lanes that receive one become active with bounce = 0.
   // MAKE_RAY = false leaves st.ray for the caller to fill in.
-  template <bool MAKE_RAY = true> RT_DEV void refill(const DeviceScene<R>& sc, const FrameParams& fp, unsigned long long total_paths, unsigned long long* path_cursor,
+  // FIXED_GRAB: the grab is kPathGrab (large frames), a constant the compiler folds, instead of fp.path_grab.
+  template <bool MAKE_RAY, bool FIXED_GRAB> RT_DEV void refill(const DeviceScene<R>& sc, const FrameParams& fp, unsigned long long total_paths, unsigned long long* path_cursor,
                      PathState<R>& st, uint32_t& bounce, bool& active) {
     const uint32_t lane = threadIdx.x & 63u;
     unsigned long long dead = __ballot(!active);
     while (dead != 0ull && !exhausted) {
       if (left == 0u) {
         unsigned long long b = 0;
-        if (lane == 0u) b = atomicAdd(path_cursor, (unsigned long long)kPathGrab);
+        const uint32_t grab = FIXED_GRAB ? kPathGrab : fp.path_grab;
+        if (lane == 0u) b = atomicAdd(path_cursor, (unsigned long long)grab);
         uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
         uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
         b = ((unsigned long long)hi << 32) | lo;
         if (b >= total_paths) { exhausted = true; break; }
-        const unsigned long long e = b + kPathGrab < total_paths ? b + kPathGrab : total_paths;
+        const unsigned long long e = b + grab < total_paths ? b + grab : total_paths;
         left = (uint32_t)(e - b);
         sample = (uint32_t)(b / fp.n_pixels);
         pixel = (uint32_t)(b - (unsigned long long)sample * fp.n_pixels);
@@ -293,7 +298,7 @@ template <class R> struct PathFeeder {
 };
 
 // Presets with nested trees want 250 registers; asking for four waves per SIMD (128 registers, some spills) is the faster trade.
-template <class R, class C>
+template <class R, class C, bool FIXED_GRAB>
 __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : 1) void k_paths_persistent(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
                                                           unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
   extern __shared__ __align__(16) uint8_t lds[];
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : 1) void k
         to_scatter = true;
       }
     }
-    feeder.template refill<false>(sc, fp, total_paths, path_cursor, st, bounce, active);
+    feeder.template refill<false, FIXED_GRAB>(sc, fp, total_paths, path_cursor, st, bounce, active);
     RT_STAMP(0);
     if (__ballot(active) == 0ull) break;
     const PrimedStream rng(Stream(fp.seed, st.pixel, st.sample, bounce, to_scatter ? STAGE_SCATTER : STAGE_CAMERA), to_scatter ? resume : 0u, kBlocksPerTurn);
@@ -389,7 +394,7 @@ constexpr uint32_t kRestartLanes = RT_RESTART_LANES;
 constexpr int kBoxStepsPerTurn = RT_BOX_STEPS;
 constexpr int kTurnsPerCheck = RT_TURNS;
 
-template <class R, class C>
+template <class R, class C, bool FIXED_GRAB>
 __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES : (C::has(F_NOISE) ? RT_STEP_WAVES_FULL : RT_STEP_WAVES)) void k_paths_stepwise(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
                                                         unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
   extern __shared__ __align__(16) uint8_t lds[];
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
           to_scatter = true;
         }
       }
-      feeder.template refill<false>(sc, fp, total_paths, path_cursor, st, bounce, active);
+      feeder.template refill<false, FIXED_GRAB>(sc, fp, total_paths, path_cursor, st, bounce, active);
       if (i < 0 && active) {  // one Philox pass: scatter draw of the continuing lanes, pixel jitter of the new ones
         const PrimedStream rng(Stream(fp.seed, st.pixel, st.sample, bounce, to_scatter ? STAGE_SCATTER : STAGE_CAMERA), to_scatter ? resume : 0u, kBlocksPerRestart);
         if (to_scatter) {

@@ -232,6 +232,11 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
 #endif
     const uint32_t bpc = resident_blocks(im.table.resident_blocks_per_cu(3, im.lds_bytes));
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->n_cus * bpc, (total_paths + kBlock - 1) / kBlock));
+    {  // at least 32 grabs per wave, in whole waves of paths
+      const uint64_t waves = (uint64_t)grid * (kBlock / 64u);
+      const uint64_t per = total_paths / (waves * 32u);
+      fp.path_grab = (uint32_t)std::min<uint64_t>(kPathGrab, std::max<uint64_t>(64u, per / 64u * 64u));
+    }
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     if (p.max_depth > 0 && total_paths > 0)
       im.table.paths_persistent(grid, im.lds_bytes, c->stream, im.dev, fp, total_paths, c->d_ray_count + 8, c->d_ray_count, accum);
