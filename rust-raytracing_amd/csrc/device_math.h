@@ -186,10 +186,15 @@ RT_DEV uint64_t word_at(const Stream& s, uint32_t slot) {
   return ((uint64_t)hj << 32) | lj;
 }
 RT_DEV double gen_log01(const Stream& s, uint32_t slot, double) { return rt_log((double)(word_at(s, slot) >> 11) * 0x1.0p-53); }
+// Only the high word of the draw is generated: U moves by less than 2^-32, ln(U) by less than 2^-32 / U in absolute terms, far
+// below the resolution of a float path length, and the second Philox block per medium crossing is saved.
 RT_DEV float gen_log01(const Stream& s, uint32_t slot, float) {
-  uint64_t k = word_at(s, slot) >> 11;
-  if (k >= (1ull << 52)) return log1pf(-((float)((1ull << 53) - k) * 0x1.0p-53f));
-  return rt_log((float)k * 0x1.0p-53f);
+  uint32_t h[4];
+  s.hi(slot >> 2, h);
+  const uint32_t j = slot & 3u;
+  const uint32_t hj = j == 0 ? h[0] : j == 1 ? h[1] : j == 2 ? h[2] : h[3];
+  if (hj >= 0x80000000u) return log1pf(-((float)(0u - hj) * 0x1.0p-32f));  // 1 - U = (2^32 - hj) / 2^32, exact before the conversion
+  return rt_log((float)hj * 0x1.0p-32f);
 }
 
 // src/vec3.rs:81-88: first candidate (three draws in [-1,1)) inside the unit ball; candidate c is block c of the stream.
