@@ -103,7 +103,7 @@ def test_first_hit_f32_within_tolerance(gpu, rtamd, oracle, earth_rgb, name):
     assert np.quantile(t_err, 0.999) < 1e-5, (name, np.quantile(t_err, 0.999), t_err.max())
 
 
-@pytest.mark.parametrize("name", ["cornell-box", "cornell-smoke", "simple-light", "random"])
+@pytest.mark.parametrize("name", ["cornell-box", "cornell-smoke", "simple-light", "random", "final-scene"])
 def test_first_hit_f32_as_rendered(gpu, rtamd, oracle, earth_rgb, name):
     """The records the f32 render kernels build (table of planar sides for the Cornell scenes, deferred records elsewhere): rays
     from everywhere inside the scene, so that box sides are met from both sides and under RotateY + Translate."""
@@ -115,14 +115,15 @@ def test_first_hit_f32_as_rendered(gpu, rtamd, oracle, earth_rgb, name):
     oh = os_.first_hit(rays, seed=3, precision=1)
     gh = gpu.trace_batch(rays, precision=rtamd.F32, seed=3, as_rendered=True)
     frac, t_err, p_err, n_err, ok = compare(gh, oh, 1e-5, False, name)
-    assert frac > (0.995 if name != "cornell-smoke" else 0.98), "%s: only %.4f of f32 rays agree in ids and front_face" % (name, frac)
+    # final-scene: its nested trees are dissolved in the f32 image, the sphere cluster's wrappers folded into the sphere centres
+    assert frac > (0.995 if name not in ("cornell-smoke", "final-scene") else 0.98), "%s: only %.4f of f32 rays agree in ids and front_face" % (name, frac)
     # origins anywhere, surfaces at any distance: the f32 error of t is that of the hit point (coordinates of a few hundred) over
     # the length of the direction, so it is judged as a distance relative to the scene's extent, like p
     d_len = np.linalg.norm(rays["d"][ok], axis=1)
     scale = np.maximum(np.abs(oh["p"][ok]).max(axis=1), 1.0)
     dist_err = np.abs(gh["t"][ok] - oh["t"][ok]) * d_len / scale
     # `random` stands on a sphere of radius 1000: points near the origin carry the f32 error of that radius
-    tol = 1e-5 if name != "random" else 1e-4
+    tol = 1e-5 if name not in ("random", "final-scene") else 1e-4
     assert np.quantile(dist_err, 0.999) < tol, (name, np.quantile(dist_err, 0.999), dist_err.max())
     assert np.quantile(n_err, 0.999) < tol, (name, np.quantile(n_err, 0.999), n_err.max())
     assert np.quantile(p_err, 0.999) < tol, (name, np.quantile(p_err, 0.999), p_err.max())
