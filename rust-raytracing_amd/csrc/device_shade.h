@@ -89,6 +89,13 @@ template <class R> RT_DEV R schlick_reflectance(R cosine, R ref_idx) {  // src/m
   return r0 + ((R)1 - r0) * (x * x4);
 }
 
+// Colour of a material whose `texture` field is a texture index, or ~index when that texture is a solid colour, which the
+// material then carries in `albedo` (scenes without any other kind of texture never look at the texture records).
+template <class R, class C> RT_DEV V3<R> material_color(const SceneView<R, C>& sv, const DMaterial<R>& m, const Rec<R>& rec) {
+  if (!C::has(F_CHECKER | F_NOISE | F_IMAGE) || 0 > m.texture) return V3<R>(m.albedo[0], m.albedo[1], m.albedo[2]);
+  return texture_value<R, C, 0>(sv, m.texture, rec.u, rec.v, rec.p);
+}
+
 // material.emitted + material.scatter for a final hit record (src/render.rs:162-176).
 // Returns true when a scattered ray exists; `emitted` is always written.
 template <class R, class C, class S>
@@ -104,7 +111,7 @@ RT_DEV bool shade_hit(const SceneView<R, C>& sv, const Ray<R>& ray_in, Rec<R>& r
       V3<R> dir = rec.n + random_unit_vector<R>(rng);
       if (near_zero(dir)) dir = rec.n;
       scattered.d = dir;
-      attenuation = texture_value<R, C, 0>(sv, m.texture, rec.u, rec.v, rec.p);
+      attenuation = material_color<R, C>(sv, m, rec);
       return true;
     }
     case MAT_METAL: if constexpr (C::has(F_METAL)) {  // src/material.rs:75-90
@@ -126,12 +133,12 @@ RT_DEV bool shade_hit(const SceneView<R, C>& sv, const Ray<R>& ray_in, Rec<R>& r
       return true;
     } break;
     case MAT_LIGHT: {  // src/material.rs:159-167
-      emitted = texture_value<R, C, 0>(sv, m.texture, rec.u, rec.v, rec.p);
+      emitted = material_color<R, C>(sv, m, rec);
       return false;
     }
     case MAT_ISOTROPIC: if constexpr (C::has(F_MEDIUM)) {  // src/material.rs:186-195
       scattered.d = random_in_unit_sphere<R>(rng);
-      attenuation = texture_value<R, C, 0>(sv, m.texture, rec.u, rec.v, rec.p);
+      attenuation = material_color<R, C>(sv, m, rec);
       return true;
     } break;
     default: break;

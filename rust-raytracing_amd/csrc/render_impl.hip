@@ -148,6 +148,13 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
     M[i].tag = s.materials[i].tag; M[i].texture = s.materials[i].texture;
     for (int k = 0; k < 3; ++k) M[i].albedo[k] = (R)s.materials[i].albedo[k];
     M[i].fuzz = (R)s.materials[i].fuzz; M[i].ir = (R)s.materials[i].ir;
+    // a solid colour is carried in the material itself (texture = ~index): the shading code then reads one record, not two
+    const int tag = s.materials[i].tag, tx = s.materials[i].texture;
+    if ((tag == RT_MAT_LAMBERTIAN || tag == RT_MAT_DIFFUSE_LIGHT || tag == RT_MAT_ISOTROPIC) && tx >= 0 && tx < s.n_textures &&
+        s.textures[tx].tag == RT_TEX_SOLID) {
+      for (int k = 0; k < 3; ++k) M[i].albedo[k] = (R)s.textures[tx].color[k];
+      M[i].texture = ~tx;
+    }
   }
   auto* T = reinterpret_cast<DTexture<R>*>(blob.data() + lay.textures_off);
   for (int i = 0; i < s.n_textures; ++i) {
