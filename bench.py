@@ -200,7 +200,9 @@ def main():
                 k = json.load(f)["kernels"].get("k_paths_persistent", {})
             if persistent and (args.scene, args.precision) == ("cornell-box", "f32") and "valu_insts_per_simd_cycle" in k:
                 issue = {"valu_insts_per_simd_cycle": k["valu_insts_per_simd_cycle"], "salu_insts_per_cu_cycle": k.get("salu_insts_per_cu_cycle"),
-                         "lanes_active_of_64": k.get("lanes_active_per_valu_cycle"), "source": "profiles/r1_pmc.json",
+                         "lanes_active_of_64": k.get("lanes_active_per_valu_cycle"),
+                         "waves_per_simd": (k["SQ_WAVES"] / 1024.0) if "SQ_WAVES" in k else None,  # one persistent launch: all resident
+                         "source": "profiles/r1_pmc.json",
                          "note": "the issue-rate microbenchmark (profiles/valu_microbench.txt) sustains 0.40 f32 FMAs and about 0.25-0.33 "
                                  "integer/compare/select instructions per SIMD cycle"}
         except (OSError, KeyError, ValueError):
