@@ -239,10 +239,12 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
 #endif
     const uint32_t bpc = resident_blocks(im.table.resident_blocks_per_cu(3, im.lds_bytes));
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->n_cus * bpc, (total_paths + kBlock - 1) / kBlock));
-    {  // at least 32 grabs per wave, in whole waves of paths
+    {  // about 16 grabs per wave, but never under 256 paths: the cursor is one address, and at the path rate of the small
+       // scenes grabs of 64 or 128 paths from 7000 waves pile up on it (measured: 1080p x 16 spp ran a third slower)
       const uint64_t waves = (uint64_t)grid * (kBlock / 64u);
-      const uint64_t per = total_paths / (waves * 32u);
-      fp.path_grab = (uint32_t)std::min<uint64_t>(kPathGrab, std::max<uint64_t>(64u, per / 64u * 64u));
+      const char* e = getenv("RTAMD_GRABS_PER_WAVE");
+      const uint64_t per = total_paths / (waves * (e ? (uint64_t)std::max(1, atoi(e)) : 16u));
+      fp.path_grab = (uint32_t)std::min<uint64_t>(kPathGrab, std::max<uint64_t>(e ? 64u : 256u, per / 64u * 64u));
     }
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     if (p.max_depth > 0 && total_paths > 0)
