@@ -61,6 +61,13 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
   if (uniform_preset && sizeof(R) == sizeof(float) && !getenv("RTAMD_NO_FLAT")) {
     for (const TmpLink& l : links)
       if (l.hit & LEAF_FLAG) flat.push_back(l.hit);
+    // a tree may hold the same object more than once (a one-object tree tests it twice, src/bvh.rs:38): testing it again gives
+    // the same distance, which the closed range accepts again, so only its last visit is kept
+    for (size_t k = 0; k < flat.size();) {
+      bool again = false;
+      for (size_t m = k + 1; m < flat.size(); ++m) again = again || flat[m] == flat[k];
+      if (again) flat.erase(flat.begin() + (long)k); else ++k;
+    }
     if (flat.size() > kFlatMaxLeaves) flat.clear();
   }
   // plain rectangles leave the list of leaf words for per-axis lists of ready-made records
