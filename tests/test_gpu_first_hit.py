@@ -148,3 +148,27 @@ def test_first_hit_known_answers(gpu, rtamd, oracle):
         assert np.allclose(h["n"][0], (0, 0, -1))
         assert h["obj"][1] == 2 and abs(h["t"][1] - 227.0) < 227 * tol and h["material"][1] == 3
         assert abs(h["u"][1] - (278 - 213) / 130.0) < 1e-6 and abs(h["v"][1] - (279.5 - 227) / 105.0) < 1e-6
+
+
+@pytest.mark.parametrize("name,switch", [("random", "RTAMD_NO_CAMERA_ORDER"), ("random", "RTAMD_REFERENCE_TREE"),
+                                         ("final-scene", "RTAMD_KEEP_NESTED"), ("cornell-box", "RTAMD_NO_FLAT")])
+def test_f32_tree_variants_agree(gpu, rtamd, oracle, earth_rgb, name, switch, monkeypatch):
+    """The closest hit does not depend on the tree: the f32 image built with one of the library's upload-time choices switched
+    off (child order, own tree, dissolved nested trees, flat leaf lists) reports the same hits as the default image."""
+    hs, _ = make_pair(rtamd, oracle, name, earth=earth_rgb)
+    rng = np.random.default_rng(97531)
+    lo, hi = SCENE_BOXES[name]
+    rays = random_rays(rng, 100_000, lo, hi)
+    gpu.upload(hs)
+    a = gpu.trace_batch(rays, precision=rtamd.F32, seed=5, as_rendered=True)
+    monkeypatch.setenv(switch, "1")
+    gpu.upload(hs)
+    b = gpu.trace_batch(rays, precision=rtamd.F32, seed=5, as_rendered=True)
+    monkeypatch.delenv(switch)
+    gpu.upload(hs)
+    same = (a["hit"] == b["hit"]) & (a["obj"] == b["obj"]) & (a["sub"] == b["sub"]) & (a["side"] == b["side"])
+    assert same.mean() > 0.999, "%s with %s: %.5f of the rays agree" % (name, switch, same.mean())
+    both = same & (a["hit"] == 1)
+    t_err = np.abs(a["t"][both] - b["t"][both]) / np.maximum(np.abs(a["t"][both]), 1e-30)
+    assert np.quantile(t_err, 0.999) < 1e-4, (name, switch, np.quantile(t_err, 0.999))
+
