@@ -5,6 +5,10 @@ One process per GPU.  A step is one complete render of the frame: every rank ren
 rank 0 with one reduce over RCCL, and rank 0 converts the sums to RGB8 and copies the image to the host.  Total work is
 fixed as N grows ("strong" scaling).  Rank 0 prints one JSON line.
 
+The reference computes in f64 (src/vec3.rs:5-10), so the top-level figures (`value`, `dtype`, `roofline`) are those of the
+double-precision kernels.  The single-precision kernels are a tolerance mode: the same frame is timed with them right after,
+and reported in the `f32` sub-record with its own roofline and the error of its image against the f64 image of the same run.
+
   python bench.py --gpus 1 --steps 3 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
@@ -24,8 +28,7 @@ FLOP_WEIGHTS = {
     "translate": 11, "rotate": 29, "medium": 12, "sc_lambert": 60, "sc_metal": 75, "sc_dielectric": 55, "sc_light": 0, "sc_iso": 40,
     "tx_solid": 0, "tx_checker": 8, "tx_noise": 7 * 180 + 7, "tx_image": 10, "bg": 22,
 }
-VALU_PEAK_TFLOPS = 157.3   # MI355X FP32 vector peak
-VALU_PEAK_F64_TFLOPS = 78.6
+VALU_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}   # MI355X vector peaks
 HBM_PEAK_GBS = 8000.0
 QUEUE_BYTES_PER_RAY = {"f32": 2 * 52, "f64": 2 * 96}  # one queue entry read + one written per ray (fused pipeline)
 
@@ -34,22 +37,47 @@ def flops_per_ray(cnt):
     return sum(FLOP_WEIGHTS[k] * cnt[k] for k in FLOP_WEIGHTS) / max(1, cnt["rays"])
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_share():
+    """Cores this job may use: the affinity mask, capped by the pool's OMP_NUM_THREADS-style limit (a box's CPU share is far
+    below the machine's core count)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2)
+    for var in ("OMP_NUM_THREADS", "MAX_JOBS"):
+        v = os.environ.get(var, "")
+        if v.isdigit() and int(v) > 0:
+            n = min(n, int(v))
+            break
+    return max(1, n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scene", default="cornell-box")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--aspect", type=float, default=16.0 / 9.0)
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--depth", type=int, default=50)
-    ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--mega-grid", type=int, default=0, help="mega-spheres: side of the sphere grid (500 = one million spheres)")
+    ap.add_argument("--precision", choices=["f32", "f64", "both"], default="both",
+                    help="both = f64 headline + f32 sub-record with its image error against the f64 frame")
     ap.add_argument("--pipeline", choices=["auto", "fused", "sorted", "persistent"], default="auto")
     ap.add_argument("--samples-per-pass", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=96, help="samples per pixel of the bounded CPU sample")
-    ap.add_argument("--save", default="", help="rank 0 writes the last image here (.png/.ppm)")
+    ap.add_argument("--save", default="", help="rank 0 writes the last image of the headline precision here (.png/.ppm)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the multi-rank path on a box with fewer GPUs than ranks (sums travel through host memory)")
     args = ap.parse_args()
@@ -79,35 +107,22 @@ def main():
         else:
             dist.init_process_group(backend="gloo")
 
-    prec = rtamd.F64 if args.precision == "f64" else rtamd.F32
     pipe = {"auto": rtamd.PIPELINE_AUTO, "fused": rtamd.PIPELINE_FUSED, "sorted": rtamd.PIPELINE_SORTED,
             "persistent": rtamd.PIPELINE_PERSISTENT}[args.pipeline]
-    tdtype = torch.float64 if prec == rtamd.F64 else torch.float32
     earth = os.path.join(REPO, "rust-raytracing_amd", "assets", "earthmap.ppm")
-    scene = rtamd.Scene(args.scene, width=args.width, aspect=args.aspect, spp=args.spp, depth=args.depth, earth_path=earth)
+    t_scene = time.perf_counter()
+    scene = rtamd.Scene(args.scene, width=args.width, aspect=args.aspect, spp=args.spp, depth=args.depth, earth_path=earth,
+                        mega_grid=args.mega_grid)
+    t_scene = time.perf_counter() - t_scene
     W, H = scene.width, scene.height
     ctx = rtamd.Context(local_rank)
+    t_upload = time.perf_counter()
     ctx.upload(scene)
+    t_upload = time.perf_counter() - t_upload
     s0 = rank * args.spp // world
     s1 = (rank + 1) * args.spp // world
-    accum = torch.zeros(H * W * 4, dtype=tdtype, device=dev)
     rgb_host = torch.zeros((H, W, 3), dtype=torch.uint8).pin_memory().numpy() if rank == 0 else None  # page-locked: the copy is one DMA
-
-    def step():
-        accum.zero_()
-        torch.cuda.synchronize()  # the library renders on its own stream
-        st = ctx.render_accum(accum.data_ptr(), s0, s1, precision=prec, pipeline=pipe, samples_per_pass=args.samples_per_pass)
-        if dist is not None and args.backend == "nccl":
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: W*H*4 values, once per frame
-            torch.cuda.synchronize()
-        elif dist is not None:
-            host = accum.cpu()
-            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-            if rank == 0:
-                accum.copy_(host)
-            torch.cuda.synchronize()
-        rgb = ctx.resolve(accum.data_ptr(), W, H, args.spp, precision=prec, out=rgb_host) if rank == 0 else None
-        return st, rgb
+    persistent = args.pipeline in ("auto", "persistent")
 
     def barrier():
         torch.cuda.synchronize()
@@ -115,68 +130,160 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    stats = []
-    rgb = None
-    for _ in range(args.steps):
-        st, rgb = step()
-        stats.append(st)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    rays = float(sum(s["rays"] for s in stats))
-    bounce_ms = float(sum(s["bounce_kernel_ms"] for s in stats))
-    launches = float(sum(s["bounce_kernel_launches"] for s in stats))
-    if dist is not None:
-        red_dev = dev if args.backend == "nccl" else torch.device("cpu")
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        r = torch.tensor([rays], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        rays_all = float(r.item())
-    else:
-        rays_all = rays
+    def run_leg(name, steps, warmup):
+        """W warm-up frames, then `steps` timed frames of the whole job in arithmetic `name`; returns the figures of the leg
+        (on every rank; `accum` holds the reduced sums on rank 0)."""
+        prec = rtamd.F64 if name == "f64" else rtamd.F32
+        accum = torch.zeros(H * W * 4, dtype=torch.float64 if name == "f64" else torch.float32, device=dev)
+        # channel 3 of a pixel's slot is unused: the reduce carries the three colour sums only
+        packed = torch.zeros(H * W * 3, dtype=accum.dtype, device=dev) if dist is not None else None
+        split = {"render_s": 0.0, "reduce_s": 0.0, "resolve_s": 0.0}
+
+        def step(timed):
+            t_a = time.perf_counter()
+            accum.zero_()
+            torch.cuda.synchronize()  # the library renders on its own stream
+            st = ctx.render_accum(accum.data_ptr(), s0, s1, precision=prec, pipeline=pipe, samples_per_pass=args.samples_per_pass)
+            t_b = time.perf_counter()
+            if dist is not None:
+                packed.copy_(accum.view(-1, 4)[:, :3].reshape(-1))
+                if args.backend == "nccl":
+                    dist.reduce(packed, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: W*H*3 values, once per frame
+                else:
+                    host = packed.cpu()
+                    dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                    if rank == 0:
+                        packed.copy_(host)
+                if rank == 0:
+                    accum.view(-1, 4)[:, :3] = packed.view(-1, 3)
+                torch.cuda.synchronize()
+            t_c = time.perf_counter()
+            rgb = ctx.resolve(accum.data_ptr(), W, H, args.spp, precision=prec, out=rgb_host) if rank == 0 else None
+            t_d = time.perf_counter()
+            if timed:
+                split["render_s"] += t_b - t_a
+                split["reduce_s"] += t_c - t_b
+                split["resolve_s"] += t_d - t_c
+            return st, rgb
+
+        for _ in range(warmup):
+            step(False)
+        barrier()
+        t0 = time.perf_counter()
+        stats = []
+        rgb = None
+        for _ in range(steps):
+            st, rgb = step(True)
+            stats.append(st)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        rays = float(sum(s["rays"] for s in stats))
+        kernel_ms = float(sum(s["bounce_kernel_ms"] for s in stats))
+        launches = float(sum(s["bounce_kernel_launches"] for s in stats))
+        rays_all, elapsed_max = rays, elapsed
+        per_rank = None
+        if dist is not None:
+            red_dev = dev if args.backend == "nccl" else torch.device("cpu")
+            t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed_max = float(t.item())
+            r = torch.tensor([rays], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(r, op=dist.ReduceOp.SUM)
+            rays_all = float(r.item())
+            # per-rank split of a step (ms): kernel, render call, reduce, resolve + copy; rank 0 reports all of them
+            mine = torch.tensor([kernel_ms / steps, 1e3 * split["render_s"] / steps, 1e3 * split["reduce_s"] / steps,
+                                 1e3 * split["resolve_s"] / steps], dtype=torch.float64, device=red_dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = [[round(float(x), 3) for x in a.tolist()] for a in allr]
+        return {"name": name, "elapsed": elapsed_max, "rays": rays, "rays_all": rays_all, "kernel_ms": kernel_ms, "launches": launches,
+                "stats": stats, "rgb": None if rgb is None else rgb.copy(), "accum": accum, "split": split, "per_rank": per_rank}
+
+    def roofline_of(leg, fpr):
+        name = leg["name"]
+        if fpr is None or leg["kernel_ms"] <= 0:
+            return None
+        stats = leg["stats"]
+        achieved = fpr * leg["rays"] / (leg["kernel_ms"] * 1e-3) / 1e12
+        peak = VALU_PEAK_TFLOPS[name]
+        rays_per_sample = leg["rays_all"] / max(1, args.steps) / (W * H * args.spp)
+        traffic = None
+        issue = None
+        try:  # counters of the same kernel on this frame, collected by tools/profile_round.sh (separate rocprofv3 passes)
+            with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
+                t = json.load(f).get("%s_%s_%s" % (args.scene, name, "persistent" if persistent else args.pipeline))
+            if t is not None:  # bytes per frame at the profiled sample count -> per launch of this run
+                traffic = t["bytes_per_frame"] * (args.spp / t["spp"]) * (s1 - s0) / args.spp / (leg["launches"] / max(1, args.steps))
+                with open(os.path.join(REPO, "profiles", "%s_pmc.json" % t["from"])) as f:
+                    k = json.load(f)["kernels"]
+                k = k.get("k_paths_persistent") or k.get("k_paths_stepwise") or {}
+                if persistent and "valu_insts_per_simd_cycle" in k:
+                    issue = {"valu_insts_per_simd_cycle": k["valu_insts_per_simd_cycle"], "salu_insts_per_cu_cycle": k.get("salu_insts_per_cu_cycle"),
+                             "lanes_active_of_64": k.get("lanes_active_per_valu_cycle"),
+                             "source": "profiles/%s_pmc.json" % t["from"]}
+        except (OSError, KeyError, ValueError):
+            pass
+        # bytes the algorithm has to move per ray: the queue pipelines read and write one queue entry per ray; the persistent
+        # pipeline keeps paths in registers and only adds finished radiance terms to the pixel sums (4 values per path)
+        qb = (4 * (8 if name == "f64" else 4)) / rays_per_sample if persistent else QUEUE_BYTES_PER_RAY[name]
+        return {
+            "bound": "valu", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+            "flops_per_ray": fpr, "kernel": ("k_paths_stepwise" if stats[-1]["scene_in_lds"] in (5, 6, 7, 8) else "k_paths_persistent") if persistent
+            else ("k_bounce_fused" if args.pipeline == "fused" else "k_trace+k_shade"),
+            "avg_launch_ms": leg["kernel_ms"] / max(1.0, leg["launches"]), "launches": leg["launches"], "issue": issue,
+            "note": "no dense contraction on this path (MFMA unused by design) and the scene is cache resident, so the vector ALU bounds it; "
+                    "peak is the vector FMA peak of the dtype; hbm = the same launches against the HBM roofline",
+            "hbm": {"bound": "hbm", "achieved": qb * leg["rays"] / (leg["kernel_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": qb * leg["rays"] / (leg["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_ray": qb},
+        }
+
+    head_name = "f32" if args.precision == "f32" else "f64"
+    head = run_leg(head_name, args.steps, args.warmup)
+    side = run_leg("f32", args.steps, args.warmup) if args.precision == "both" else None
 
     if rank == 0:
+        headline = (args.scene, args.width, args.spp) == ("cornell-box", 1920, 1024)
         out = {
-            "metric": "Mrays/s cornell_box 1080p 1024spp" if (args.scene, args.width, args.spp) == ("cornell-box", 1920, 1024)
-            else "Mrays/s %s %dx%d %dspp" % (args.scene, W, H, args.spp),
-            "value": rays_all / elapsed / 1e6,
+            "metric": "Mrays/s cornell_box 1080p 1024spp" if headline else "Mrays/s %s %dx%d %dspp" % (args.scene, W, H, args.spp),
+            "value": head["rays_all"] / head["elapsed"] / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / max(1, args.steps),
+            "ms_per_step": 1e3 * head["elapsed"] / max(1, args.steps),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": args.precision,
+            "dtype": head_name,
             "data": "synthetic",
             "config": {"workload": "%s %dx%d, %d spp, depth %d, samples sharded over ranks, one reduce to rank 0" % (args.scene, W, H, args.spp, args.depth),
-                       "pipeline": args.pipeline, "rays_per_step": rays_all / max(1, args.steps),
-                       "rays_per_camera_sample": rays_all / max(1, args.steps) / (W * H * args.spp),
-                       "lds_bytes": stats[-1]["lds_bytes"], "scene_in_lds": stats[-1]["scene_in_lds"]},
+                       "pipeline": args.pipeline, "rays_per_step": head["rays_all"] / max(1, args.steps),
+                       "rays_per_camera_sample": head["rays_all"] / max(1, args.steps) / (W * H * args.spp),
+                       "lds_bytes": head["stats"][-1]["lds_bytes"], "scene_in_lds": head["stats"][-1]["scene_in_lds"],
+                       "scene_build_s": t_scene, "upload_s": t_upload},
         }
+        if world > 1:
+            out["per_rank_ms"] = {"columns": ["kernel", "render_call", "reduce", "resolve_and_copy"], "ranks": head["per_rank"]}
         cpu = None
         cnt = None
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(REPO, "tests"))
             import oracle_lib  # the checker, used here only as the timed CPU baseline
-            threads = max(1, min(os.cpu_count() or 2, 16) - 1)  # num_cpus - 1 (src/render.rs:184), capped to this job's CPU share
+            share = cpu_share()
+            threads = max(1, share - 1)  # num_cpus - 1 worker threads (src/render.rs:184) of the cores this job may use
             earth_rgb = None
             if args.scene in ("earth", "final-scene"):
                 earth_rgb = rtamd.load_ppm(earth)
-            osc = oracle_lib.OracleScene(args.scene, width=args.width, aspect=args.aspect, spp=args.spp, depth=args.depth, earth=earth_rgb)
+            osc = oracle_lib.OracleScene(args.scene, width=args.width, aspect=args.aspect, spp=args.spp, depth=args.depth, earth=earth_rgb,
+                                         mega_grid=args.mega_grid)
             _, cnt, secs = osc.render(0, args.cpu_spp, seed=0, threads=threads)
             cpu = {"value": cnt["rays"] / secs / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
                    "sample": "same scene and frame, samples 0..%d of %d per pixel (%d rays), C++ f64 restatement of the reference with its "
-                             "row-block schedule; the Rust binary cannot be built here" % (args.cpu_spp, args.spp, cnt["rays"]),
-                   "seconds": secs, "host_cpus": os.cpu_count()}
+                             "row-block schedule on num_cpus-1 threads; the Rust binary cannot be built here" % (args.cpu_spp, args.spp, cnt["rays"]),
+                   "seconds": secs, "cpu_model": cpu_model(), "cpus_usable": share, "cpus_machine": os.cpu_count()}
+            out["vs_cpu_baseline"] = out["value"] / cpu["value"]
         out["cpu_baseline"] = cpu
-        # Roofline of the dominant kernel (the one launch of k_paths_persistent, or the per-bounce kernels of the queue pipelines):
+        # Roofline of the dominant kernel (the one launch of the path kernel, or the per-bounce kernels of the queue pipelines):
         # algorithmic flops per ray x rays / kernel time measured by the library with HIP events on its own stream.
         fpr = flops_per_ray(cnt) if cnt else None
         if fpr is None:
@@ -185,48 +292,34 @@ def main():
                     fpr = json.load(f).get(args.scene)
             except OSError:
                 fpr = None
-        persistent = args.pipeline in ("auto", "persistent")
-        traffic = None
-        try:
-            with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
-                t = json.load(f).get("%s_%s_%s" % (args.scene, args.precision, "persistent" if persistent else args.pipeline))
-            if t is not None:  # bytes per frame at the profiled sample count -> per launch of this run
-                traffic = t["bytes_per_frame"] * (args.spp / t["spp"]) * (s1 - s0) / args.spp / (launches / max(1, args.steps))
-        except (OSError, KeyError):
-            pass
-        issue = None
-        try:  # counters of the same kernel on the headline frame, collected by tools/profile_round.sh (separate rocprofv3 passes)
-            with open(os.path.join(REPO, "profiles", "r1_pmc.json")) as f:
-                k = json.load(f)["kernels"].get("k_paths_persistent", {})
-            if persistent and (args.scene, args.precision) == ("cornell-box", "f32") and "valu_insts_per_simd_cycle" in k:
-                issue = {"valu_insts_per_simd_cycle": k["valu_insts_per_simd_cycle"], "salu_insts_per_cu_cycle": k.get("salu_insts_per_cu_cycle"),
-                         "lanes_active_of_64": k.get("lanes_active_per_valu_cycle"),
-                         "waves_per_simd": (k["SQ_WAVES"] / 1024.0) if "SQ_WAVES" in k else None,  # one persistent launch: all resident
-                         "source": "profiles/r1_pmc.json",
-                         "note": "the issue-rate microbenchmark (profiles/valu_microbench.txt) sustains 0.40 f32 FMAs and about 0.25-0.33 "
-                                 "integer/compare/select instructions per SIMD cycle"}
-        except (OSError, KeyError, ValueError):
-            pass
-        if fpr is not None and bounce_ms > 0:
-            achieved = fpr * rays / (bounce_ms * 1e-3) / 1e12
-            peak = VALU_PEAK_F64_TFLOPS if args.precision == "f64" else VALU_PEAK_TFLOPS
-            # bytes the algorithm has to move per ray: the queue pipelines read and write one queue entry per ray; the persistent
-            # pipeline keeps paths in registers and only adds finished radiance terms to the pixel sums (16 bytes per path)
-            qb = 16.0 / (rays_all / max(1, args.steps) / (W * H * args.spp)) if persistent else QUEUE_BYTES_PER_RAY[args.precision]
-            out["roofline"] = {
-                "bound": "valu", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                "flops_per_ray": fpr, "kernel": "k_paths_persistent" if persistent else ("k_bounce_fused" if args.pipeline == "fused" else "k_trace+k_shade"),
-                "avg_launch_ms": bounce_ms / max(1.0, launches), "launches": launches, "issue": issue,
-                "note": "no dense contraction on this path (MFMA unused by design) and the scene is cache resident, so the vector ALU bounds it; "
-                        "peak is the FP32 (FP64) vector FMA peak; hbm = the same launches against the HBM roofline",
-                "hbm": {"bound": "hbm", "achieved": qb * rays / (bounce_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": qb * rays / (bounce_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_ray": qb},
+        out["roofline"] = roofline_of(head, fpr)
+        if side is not None:
+            # error of the f32 frame against the f64 frame of this run, both at the full sample count: linear radiance per pixel
+            # (sum / spp) clamped to [0, 1] as color_to_rgb does before its gamma (src/color.rs:20-25)
+            a64 = (head["accum"].view(-1, 4)[:, :3] / args.spp).clamp(0.0, 1.0)
+            a32 = (side["accum"].view(-1, 4)[:, :3].double() / args.spp).clamp(0.0, 1.0)
+            m64, m32 = a64.mean(0), a32.mean(0)
+            diff8 = np.abs(head["rgb"].astype(np.int16) - side["rgb"].astype(np.int16))
+            out["f32"] = {
+                "value": side["rays_all"] / side["elapsed"] / 1e6, "unit": "Mrays/s", "dtype": "f32",
+                "ms_per_step": 1e3 * side["elapsed"] / max(1, args.steps), "steps": args.steps, "warmup": args.warmup,
+                "roofline": roofline_of(side, fpr),
+                "image_error_vs_f64": {
+                    "samples_per_pixel": args.spp,
+                    "mean_f64": [float(x) for x in m64], "mean_f32": [float(x) for x in m32],
+                    "mean_error_rel": [float(x) for x in ((m32 - m64).abs() / m64.clamp_min(1e-12))],
+                    "rmse": [float(x) for x in ((a32 - a64) ** 2).mean(0).sqrt()],
+                    "rgb8_max_abs_diff": int(diff8.max()), "rgb8_frac_bytes_differing": float((diff8 > 0).mean()),
+                    "rays_rel_diff": abs(side["rays_all"] - head["rays_all"]) / head["rays_all"],
+                    "note": "per channel, linear radiance clamped to [0,1]; both frames use the same random streams, so the difference is "
+                            "rounding plus the paths that part where single precision resolves an edge differently",
+                },
             }
-        else:
-            out["roofline"] = None
+            if world > 1:
+                out["f32"]["per_rank_ms"] = {"columns": ["kernel", "render_call", "reduce", "resolve_and_copy"], "ranks": side["per_rank"]}
         print(json.dumps(out), flush=True)
-        if args.save and rgb is not None:
-            rtamd.save_image(args.save, rgb)
+        if args.save and head["rgb"] is not None:
+            rtamd.save_image(args.save, head["rgb"])
     ctx.close()
     if dist is not None:
         dist.barrier()

@@ -207,7 +207,7 @@ template <class R> struct Builder {
         boxes1.add(std::make_shared<BoxShape<R>>(V3<R>((R)x0, (R)y0, (R)z0), V3<R>((R)x1, (R)y1, (R)z1), ground));
       }
     for (size_t i = 0; i < boxes1.objects.size(); ++i) boxes1.objects[i]->label(-1, (int)i);
-    sc.world.add(std::make_shared<BVHNode<R>>(boxes1.objects, 0, boxes1.objects.size(), (R)0, (R)1, bvh_rng));
+    sc.world.add(std::make_shared<BVHNode<R>>(boxes1.objects, 0, boxes1.objects.size(), (R)0, (R)1, bvh_rng, 1));
     auto lt = light(V3<R>(7, 7, 7));
     sc.world.add(std::make_shared<XZRect<R>>(123, 423, 147, 412, 554, lt));
     V3<R> center1(400, 400, 400);
@@ -227,7 +227,7 @@ template <class R> struct Builder {
     auto white = lambert(V3<R>(0.73, 0.73, 0.73));
     for (int i = 0; i < 1000; ++i) boxes2.add(sphere(aux_random_range(0.0, 165.0), 10, white));
     for (size_t i = 0; i < boxes2.objects.size(); ++i) boxes2.objects[i]->label(-1, (int)i);
-    HPtr<R> h = std::make_shared<BVHNode<R>>(boxes2.objects, 0, boxes2.objects.size(), (R)0, (R)1, bvh_rng);
+    HPtr<R> h = std::make_shared<BVHNode<R>>(boxes2.objects, 0, boxes2.objects.size(), (R)0, (R)1, bvh_rng, 1);
     h = std::make_shared<RotateY<R>>(h, (R)15);
     sc.world.add(std::make_shared<Translate<R>>(h, V3<R>(-100, 270, 395)));
   }

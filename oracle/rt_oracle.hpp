@@ -238,8 +238,13 @@ template <class R> struct Ray {
 };
 
 // Per-query context: the MEDIA random stream of the current (pixel,sample,bounce).
+// `visit`: which call of a repeated object this is.  A one-object BVH node holds the same child twice (bvh.rs:38) and hits it
+// twice (bvh.rs:114-116); the reference's ConstantMedium draws a fresh random number on every call (constant_medium.rs:50,91), so
+// with addressed draws the second call needs a slot of its own: bit 0 = second call in a node of the world's tree, bit 1 =
+// second call in a node of a nested tree.
 struct HitCtx {
   Stream* media;
+  uint32_t visit = 0;
 };
 
 // ---------------------------------------------------------------------------
@@ -754,7 +759,8 @@ template <class R> struct ConstantMedium : Hittable<R> {
     if (rec1.t < (R)0) rec1.t = 0;
     R ray_length = ray.direction.length();
     R distance_inside_boundary = (rec2.t - rec1.t) * ray_length;
-    R hit_distance = negative_inverse_density * std::log(gen01_at<R>(*ctx.media, (uint32_t)obj));  // draw slot = this object's index
+    // draw slot = this object's index, plus the visit bits (an independent draw per call, as thread_rng() gives the reference)
+    R hit_distance = negative_inverse_density * std::log(gen01_at<R>(*ctx.media, (uint32_t)obj | (ctx.visit << 28)));
     if (hit_distance > distance_inside_boundary) return false;
     rec.t = rec1.t + hit_distance / ray_length;
     rec.p = ray.at(rec.t);
@@ -842,8 +848,9 @@ struct Pcg32 {
 template <class R> struct BVHNode : Hittable<R> {
   HPtr<R> left, right;
   Aabb<R> box;
+  int level = 0;  // 0: the world's tree (render.rs:211); 1: a tree that is an object of the world (scenes.rs:449,548)
   // bvh.rs:19-76.  `axis_rng` stands in for thread_rng().gen_range(0..=2).
-  BVHNode(const std::vector<HPtr<R>>& src, size_t begin, size_t end, R time0, R time1, Pcg32& axis_rng) {
+  BVHNode(const std::vector<HPtr<R>>& src, size_t begin, size_t end, R time0, R time1, Pcg32& axis_rng, int tree_level = 0) : level(tree_level) {
     std::vector<HPtr<R>> objs(src.begin() + begin, src.begin() + end);
     int axis = (int)axis_rng.gen_range_u32_inclusive(0, 2);
     auto key = [axis](const HPtr<R>& h) -> R {  // bvh.rs:83-94 (boxes at time (0,0))
@@ -860,8 +867,8 @@ template <class R> struct BVHNode : Hittable<R> {
     } else {
       std::stable_sort(objs.begin(), objs.end(), less);  // slice::sort_by is stable
       size_t mid = n / 2;
-      left = std::make_shared<BVHNode>(objs, 0, mid, time0, time1, axis_rng);
-      right = std::make_shared<BVHNode>(objs, mid, n, time0, time1, axis_rng);
+      left = std::make_shared<BVHNode>(objs, 0, mid, time0, time1, axis_rng, tree_level);
+      right = std::make_shared<BVHNode>(objs, mid, n, time0, time1, axis_rng, tree_level);
     }
     auto bl = left->bounding_box(time0, time1);
     auto br = right->bounding_box(time0, time1);
@@ -877,7 +884,10 @@ template <class R> struct BVHNode : Hittable<R> {
     if (!box.hit(ray, t_min, t_max)) return false;
     bool hit_left = left->hit(ray, t_min, t_max, rec, ctx);
     R right_t_max = hit_left ? rec.t : t_max;
+    const uint32_t outer = ctx.visit;
+    if (right.get() == left.get()) ctx.visit = outer | (1u << level);  // the same object a second time
     bool hit_right = right->hit(ray, t_min, right_t_max, rec, ctx);
+    ctx.visit = outer;
     return hit_left || hit_right;
   }
   std::optional<Aabb<R>> bounding_box(R, R) const override { return box; }  // bvh.rs:121-123

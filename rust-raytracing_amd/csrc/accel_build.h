@@ -82,17 +82,23 @@ class FastTreeBuilder {
  private:
   const rt_scene_desc& s_;
   std::vector<Box3d> nested_box_;
+  std::vector<char> twice_;  // objects whose leaf the reference's tree visits twice and whose second visit matters (media)
   struct Node {
     Box3d box;
     int left = -1, right = -1, obj = -1;
   };
 
   // Objects of one reference tree, each once, ordered by the LAST time the reference's walk visits them.
-  static std::vector<int> leaves_in_visiting_order(const std::vector<TmpLink>& ref, int start, int n_objects) {
+  std::vector<int> leaves_in_visiting_order(const std::vector<TmpLink>& ref, int start, int n_objects) {
     std::vector<int> seq;
+    if (twice_.empty()) twice_.assign((size_t)n_objects, 0);
     for (int i = start; i >= 0;) {
       const TmpLink& l = ref[(size_t)i];
-      if (l.hit & LEAF_FLAG) { seq.push_back((int)(l.hit & LEAF_INDEX_MASK)); i = l.miss; }
+      if (l.hit & LEAF_FLAG) {
+        seq.push_back((int)(l.hit & LEAF_INDEX_MASK));
+        if (l.hit & LEAF_SECOND) twice_[(size_t)(l.hit & LEAF_INDEX_MASK)] = 1;  // a medium the reference's tree visits twice
+        i = l.miss;
+      }
       else i = (int)l.hit;
     }
     std::vector<int> out;
@@ -271,6 +277,12 @@ class FastTreeBuilder {
     const int me = (int)out.size();
     if (nd.obj >= 0) {
       l.hit = leaf_word(nd.obj);
+      if (!twice_.empty() && twice_[(size_t)nd.obj]) {  // both visits, the second right behind the first
+        l.miss = me + 1;
+        out.push_back(l);
+        l.hit |= LEAF_SECOND;
+        l.miss = next;
+      }
       out.push_back(l);
       return me;
     }
@@ -319,6 +331,12 @@ class FastTreeBuilder {
       TmpLink l{};
       l.hit = leaf_word(nodes[0].obj);
       l.miss = LINK_END; l.depth = 1; l.tree = tree;
+      if (!twice_.empty() && twice_[(size_t)nodes[0].obj]) {
+        l.miss = 2;
+        out.push_back(l);
+        l.hit |= LEAF_SECOND;
+        l.miss = LINK_END;
+      }
       out.push_back(l);
       return;
     }

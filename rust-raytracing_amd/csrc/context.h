@@ -99,7 +99,8 @@ inline uint32_t grid_for(const rt_context* c, uint64_t n, uint32_t blocks_per_cu
   return (uint32_t)((g + kSegments - 1) / kSegments * kSegments);  // whole workgroups per queue segment
 }
 
-// Implemented once per precision (rt_f32.hip / rt_f64.hip).
+// Implemented once per precision (render_impl.hip).
+template <class R> void layout_sections(rtd::BlobLayout& lay);
 template <class R>
 int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink>& links, int root_link, const std::vector<int>& sub_root_of_object,
                 int preset, SceneImage<R>& im);

@@ -17,7 +17,16 @@ constexpr int LINK_END = -1;
 constexpr uint32_t LEAF_FLAG = 0x80000000u;    // hit word of a leaf entry
 constexpr uint32_t LEAF_SIMPLE = 0x40000000u;  // object has no transform / medium / nested tree: test the shape directly
 constexpr uint32_t LEAF_NESTED = 0x20000000u;  // object is a tree of its own (OBJ_SUB_BVH)
-constexpr uint32_t LEAF_INDEX_MASK = 0x1FFFFFFFu;
+// Second visit of the object of a one-object node: BVHNode::new gives such a node the same child twice (src/bvh.rs:38) and
+// BVHNode::hit calls it twice (src/bvh.rs:114-116).  A deterministic shape returns the same record again and the visit is dropped
+// at upload; a ConstantMedium draws a fresh random number on every call (src/constant_medium.rs:91), so its second visit stays
+// in the list and reads a draw slot of its own.
+constexpr uint32_t LEAF_SECOND = 0x10000000u;
+constexpr uint32_t LEAF_INDEX_MASK = 0x0FFFFFFFu;
+// Draw slot of a medium's free-path sample on the MEDIA stream: the object's index, plus bit 28 on the second visit of a
+// one-object node of the main tree and bit 29 on the second visit of one inside a nested tree.
+RT_DEV uint32_t medium_slot(uint32_t obj_id, uint32_t visit) { return obj_id | (visit << 28); }
+RT_DEV uint32_t visit_bit(uint32_t leaf_word, int level) { return (leaf_word & LEAF_SECOND) ? (1u << level) : 0u; }
 
 template <class R> struct alignas(16) DLink {  // 32 B (float) / 64 B (double)
   R bmin[3];
@@ -79,9 +88,9 @@ template <class R> struct DBackground {  // src/color.rs:35-39
 struct BlobLayout {
   uint32_t links_off, shapes_off, objects_off, materials_off, textures_off, perlins_off, flat_off, total_bytes;
   uint32_t n_links, n_objects, n_materials, n_textures, n_perlins;
-  // Single-precision small scenes (flat_mode != 0): the tree's leaves as two lists.  Plain rectangles, grouped by their constant
+  // Small scenes (flat_mode != 0): the tree's leaves as lists.  Single precision: plain rectangles, grouped by their constant
   // axis (n_frect[0] YZ, [1] XZ, [2] XY), as FlatRect records at frect_off; every other leaf as its leaf word, in visiting order,
-  // at flat_off (n_flat of them).
+  // at flat_off (n_flat of them).  Double precision: every leaf as its leaf word, in visiting order (no FlatRect records).
   uint32_t n_flat, flat_mode, frect_off, n_frect[3];
   uint32_t faces_off;  // FlatFace records, six per object (flat_mode only)
 };
@@ -103,13 +112,14 @@ struct alignas(16) FlatRect {  // a plain rectangle ready for the test: plane co
   int32_t obj, pad0, pad1;
 };
 
-// One planar side of a rectangle or box, as the record of a hit needs it (single-precision small scenes): slot 6 * object + side,
+// One planar side of a rectangle or box, as the record of a hit needs it (small scenes, flat walk): slot 6 * object + side,
 // a rectangle's only side in slot 0.  `n` is the side's outward normal after the holder's RotateY; bits 0..3 of `flags` are the
 // holder's OBJ_* flags, bits 4..5 the side's constant axis in the shape's own frame.
-struct alignas(16) FlatFace {
-  float n[3];
+template <class R> struct alignas(16) FlatFace {  // 32 B (float) / 64 B (double)
+  R n[3];
+  R cos_theta, sin_theta, k;
   uint32_t flags;
-  float cos_theta, sin_theta, k, pad;
+  uint32_t pad[sizeof(R) == 4 ? 1 : 3];
 };
 
 // Kernel configuration: which parts of the scene grammar a kernel instantiation carries, and how it walks the tree.
@@ -209,7 +219,7 @@ template <class R, class C> struct SceneView {
   uint32_t n_flat, flat_mode;
   const FlatRect* frect;           // plain rectangles by axis (global memory, scalar loads)
   uint32_t n_frect[3];
-  const FlatFace* faces_lane;      // per-lane gathers (LDS)
+  const FlatFace<R>* faces_lane;   // per-lane gathers (LDS)
   const DShape<R>* shapes_lane;    // the same records where a lane gathers them with an index of its own (LDS in WALK_UNIFORM)
   const DObject<R>* objects_lane;
   const DMaterial<R>* materials;
@@ -282,7 +292,7 @@ template <class R, class C> RT_DEV SceneView<R, C> make_view(const DeviceScene<R
   v.objects = reinterpret_cast<const DObject<R>*>(geom + sc.lay.objects_off);
   v.shapes_lane = reinterpret_cast<const DShape<R>*>(lane + sc.lay.shapes_off);
   v.objects_lane = reinterpret_cast<const DObject<R>*>(lane + sc.lay.objects_off);
-  v.faces_lane = reinterpret_cast<const FlatFace*>(lane + sc.lay.faces_off);
+  v.faces_lane = reinterpret_cast<const FlatFace<R>*>(lane + sc.lay.faces_off);
   v.materials = reinterpret_cast<const DMaterial<R>*>(shade + (sc.lay.materials_off - shade_sub));
   v.textures = reinterpret_cast<const DTexture<R>*>(shade + (sc.lay.textures_off - shade_sub));
   v.perlins = reinterpret_cast<const DPerlin<R>*>(shade + (sc.lay.perlins_off - shade_sub));

@@ -226,12 +226,13 @@ template <class R, class C> RT_DEV bool shape_hit(const DShape<R>& s, int leaf, 
 }
 
 template <class R, class C, int LEVEL>
-RT_DEV bool traverse_lane(const SceneView<R, C>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org);
+RT_DEV bool traverse_lane(const SceneView<R, C>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org,
+                          uint32_t visit = 0u);
 
 // [Translate(] [RotateY(] geometry [))] — the part of an object below an optional ConstantMedium.
 template <class R, class C, int LEVEL>
 RT_DEV bool boundary_hit(const SceneView<R, C>& sv, const DObject<R>& ob, int obj_index, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec,
-                         Stream& media, Origin org) {
+                         Stream& media, Origin org, uint32_t visit) {
   Ray<R> moved = ray;
   Ray<R> local = ray;
   if constexpr (C::has(F_XFORM)) {
@@ -250,7 +251,7 @@ RT_DEV bool boundary_hit(const SceneView<R, C>& sv, const DObject<R>& ob, int ob
   if constexpr (C::has(F_NESTED) && LEVEL == 0) {  // nested trees do not nest further (rejected at upload)
     if (ob.flags & OBJ_SUB_BVH) {
       nested = true;
-      hit = traverse_lane<R, C, 1>(sv, ob.sub_root, local, t_min, t_max, rec, media, org);
+      hit = traverse_lane<R, C, 1>(sv, ob.sub_root, local, t_min, t_max, rec, media, org, visit);
     }
   }
   if (!nested) hit = shape_hit<R, C>(sv.shape(obj_index), obj_index, local, t_min, t_max, rec, org.leaf() == obj_index ? org.side() : -2);
@@ -274,20 +275,21 @@ RT_DEV bool boundary_hit(const SceneView<R, C>& sv, const DObject<R>& ob, int ob
 }
 
 template <class R, class C, int LEVEL>
-RT_DEV bool object_hit(const SceneView<R, C>& sv, int obj_index, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
+RT_DEV bool object_hit(const SceneView<R, C>& sv, int obj_index, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org,
+                       uint32_t visit) {
   const DObject<R> ob = sv.object(obj_index);
   if constexpr (C::has(F_MEDIUM)) {
     if (ob.flags & OBJ_MEDIUM) {  // src/constant_medium.rs:41-111
       const R inf = Lim<R>::inf();
       Rec<R> rec1, rec2;
-      if (!boundary_hit<R, C, LEVEL>(sv, ob, obj_index, ray, -inf, inf, rec1, media, Origin())) return false;
+      if (!boundary_hit<R, C, LEVEL>(sv, ob, obj_index, ray, -inf, inf, rec1, media, Origin(), visit)) return false;
       R t_after = rec1.t + (R)0.0001;
       if constexpr (Guard<R>::on) {
         // f32: beyond |t| = 1024 the spacing of floats exceeds 0.0001 and the sum rounds back to rec1.t (a fog boundary of
         // radius 5000 has t of that size); "strictly beyond the entry point" is what the reference's f64 sum means there.
         if (!(t_after > rec1.t)) t_after = nextafterf(rec1.t, Lim<float>::inf());
       }
-      if (!boundary_hit<R, C, LEVEL>(sv, ob, obj_index, ray, t_after, inf, rec2, media, Origin())) return false;
+      if (!boundary_hit<R, C, LEVEL>(sv, ob, obj_index, ray, t_after, inf, rec2, media, Origin(), visit)) return false;
       R t1 = rec1.t, t2 = rec2.t;
       if (t1 < t_min) t1 = t_min;
       if (t2 > t_max) t2 = t_max;
@@ -296,7 +298,7 @@ RT_DEV bool object_hit(const SceneView<R, C>& sv, int obj_index, const Ray<R>& r
       R ray_length = length(ray.d);
       R distance_inside_boundary = (t2 - t1) * ray_length;
       const DShape<R> ids = sv.shape(obj_index);
-      R hit_distance = ob.neg_inv_density * gen_log01(media, (uint32_t)ids.obj_id, (R)0);
+      R hit_distance = ob.neg_inv_density * gen_log01(media, medium_slot((uint32_t)ids.obj_id, visit), (R)0);
       if (hit_distance > distance_inside_boundary) return false;
       rec.t = t1 + hit_distance / ray_length;
       rec.p = ray.at(rec.t);
@@ -310,14 +312,15 @@ RT_DEV bool object_hit(const SceneView<R, C>& sv, int obj_index, const Ray<R>& r
       return true;
     }
   }
-  return boundary_hit<R, C, LEVEL>(sv, ob, obj_index, ray, t_min, t_max, rec, media, org);
+  return boundary_hit<R, C, LEVEL>(sv, ob, obj_index, ray, t_min, t_max, rec, media, org, visit);
 }
 
 template <class R, class C, int LEVEL>
-RT_DEV bool leaf_hit(const SceneView<R, C>& sv, uint32_t leaf_word, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
+RT_DEV bool leaf_hit(const SceneView<R, C>& sv, uint32_t leaf_word, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org,
+                     uint32_t visit = 0u) {
   int obj = (int)(leaf_word & LEAF_INDEX_MASK);
   if constexpr (C::has(F_XFORM) || C::has(F_MEDIUM) || C::has(F_NESTED)) {
-    if (!(leaf_word & LEAF_SIMPLE)) return object_hit<R, C, LEVEL>(sv, obj, ray, t_min, t_max, rec, media, org);
+    if (!(leaf_word & LEAF_SIMPLE)) return object_hit<R, C, LEVEL>(sv, obj, ray, t_min, t_max, rec, media, org, visit | visit_bit(leaf_word, LEVEL));
   }
   return shape_hit<R, C>(sv.shape(obj), obj, ray, t_min, t_max, rec, org.leaf() == obj ? org.side() : -2);
 }
@@ -350,7 +353,8 @@ template <> struct LaneBoxTest<float> {
 };
 
 template <class R, class C, int LEVEL>
-RT_DEV bool traverse_lane(const SceneView<R, C>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
+RT_DEV bool traverse_lane(const SceneView<R, C>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org,
+                          uint32_t visit) {
   const LaneBoxTest<R> box(ray);
   R closest = t_max;
   bool any = false;
@@ -365,7 +369,7 @@ RT_DEV bool traverse_lane(const SceneView<R, C>& sv, int start, const Ray<R>& ra
       lk = sv.link(i);
     }
     if (i < 0) break;
-    if (leaf_hit<R, C, LEVEL>(sv, lk.hit, ray, t_min, closest, rec, media, org)) { closest = rec.t; any = true; }
+    if (leaf_hit<R, C, LEVEL>(sv, lk.hit, ray, t_min, closest, rec, media, org, visit)) { closest = rec.t; any = true; }
     i = lk.miss;
   }
   return any;

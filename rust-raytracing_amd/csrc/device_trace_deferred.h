@@ -44,8 +44,8 @@ template <> struct RayInv<float> {
 
 // src/aarect.rs:88-97: distance to the plane, range test, in-plane bounds (closed).  Written without early exits: the six
 // comparisons are the reference's own (negated, so a NaN passes them as it does there) and their conjunction decides.
-template <class R, int AXIS>
-RT_DEV bool rect_t(R a0, R a1, R b0, R b1, R k, const Ray<R>& ray, const RayInv<R>& ri, R t_min, R t_max, R& t_out) {
+template <class R, int AXIS, class RI>
+RT_DEV bool rect_t(R a0, R a1, R b0, R b1, R k, const Ray<R>& ray, const RI& ri, R t_min, R t_max, R& t_out) {
   constexpr int A = (AXIS == 0) ? 1 : 0;
   constexpr int B = (AXIS == 2) ? 1 : 2;
   const R o[3] = {ray.o.x, ray.o.y, ray.o.z};
@@ -125,7 +125,7 @@ RT_DEV bool boundary_t(const DObject<R>& ob, const DShape<R>& s, const Ray<R>& r
 // One leaf of the tree (object index uniform across the wave).
 template <class R, class C>
 RT_DEV bool leaf_t(const SceneView<R, C>& sv, uint32_t leaf_word, const Ray<R>& ray, const RayInv<R>& ri, R t_min, R t_max, Stream& media, Origin org,
-                   R& t_out, int& side_out) {
+                   R& t_out, int& side_out, uint32_t visit = 0u) {
   const int obj = (int)(leaf_word & LEAF_INDEX_MASK);
   const DShape<R> s = sv.shape(obj);
   const int self_side = org.leaf() == obj ? org.side() : -2;
@@ -149,7 +149,7 @@ RT_DEV bool leaf_t(const SceneView<R, C>& sv, uint32_t leaf_word, const Ray<R>& 
           if (t1 < (R)0) t1 = (R)0;
           R ray_length = length(ray.d);
           R distance_inside_boundary = (t2 - t1) * ray_length;
-          R hit_distance = ob.neg_inv_density * gen_log01(media, (uint32_t)s.obj_id, (R)0);
+          R hit_distance = ob.neg_inv_density * gen_log01(media, medium_slot((uint32_t)s.obj_id, visit), (R)0);
           if (hit_distance > distance_inside_boundary) return false;
           t_out = t1 + hit_distance / ray_length;
           side_out = SIDE_MEDIUM;
@@ -271,7 +271,7 @@ RT_DEV bool traverse_uniform(const SceneView<R, C>& sv, int start, const Ray<R>&
       if (want == cur) {
         R t;
         int side;
-        if (leaf_t<R, C>(sv, lk.hit, ray, ri, t_min, closest, media, org, t, side)) {
+        if (leaf_t<R, C>(sv, lk.hit, ray, ri, t_min, closest, media, org, t, side, visit_bit(lk.hit, 0))) {
           closest = t;
           best_leaf = (int)(lk.hit & LEAF_INDEX_MASK);
           best_side = side;
@@ -287,12 +287,29 @@ RT_DEV bool traverse_uniform(const SceneView<R, C>& sv, int start, const Ray<R>&
   return true;
 }
 
-// ---- single-precision forms used by the flat walk ----
-// x in [lo, hi] as one median and one compare; a NaN is outside.
+// ---- forms used by the flat walk ----
+// x in [lo, hi]; a NaN is outside.  Single precision: one median and one compare.
 RT_DEV bool in_closed(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi) == x; }
+RT_DEV bool in_closed(double x, double lo, double hi) { return (x >= lo) & (x <= hi); }
+
+// Reciprocal of a direction component for the flat walk.  Single precision: the hardware estimate (1 ulp).  Double precision: the
+// IEEE quotient 1/d, which is what Aabb::hit multiplies by (src/aabb.rs:33).
+RT_DEV float flat_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+RT_DEV double flat_rcp(double x) { return 1.0 / x; }
+RT_DEV float next_up(float x) { return nextafterf(x, Lim<float>::inf()); }
+RT_DEV double next_up(double x) { return nextafter(x, Lim<double>::inf()); }
+
+// Distances along the ray as (plane - origin) * (1 / direction) in both precisions: the flat walk forms every plane distance the
+// way the reference's box test does (src/aabb.rs:33-35).  Against the quotient (k - o) / d of src/aarect.rs:89 that is one more
+// rounding, i.e. at most 1 ulp of t.
+template <class R> struct RayRcp {
+  V3<R> inv;
+  RT_DEV explicit RayRcp(V3<R> dir) : inv(flat_rcp(dir.x), flat_rcp(dir.y), flat_rcp(dir.z)) {}
+  template <int AXIS> RT_DEV R quot(R num) const { return num * (AXIS == 0 ? inv.x : AXIS == 1 ? inv.y : inv.z); }
+};
 
 template <int AXIS>
-RT_DEV bool rect_fast(float a0, float a1, float b0, float b1, float k, const Ray<float>& ray, const RayInv<float>& ri, float t_min, float t_max,
+RT_DEV bool rect_fast(float a0, float a1, float b0, float b1, float k, const Ray<float>& ray, const RayRcp<float>& ri, float t_min, float t_max,
                       float& t_out) {
   constexpr int A = (AXIS == 0) ? 1 : 0;
   constexpr int B = (AXIS == 2) ? 1 : 2;
@@ -304,23 +321,29 @@ RT_DEV bool rect_fast(float a0, float a1, float b0, float b1, float k, const Ray
   t_out = t;
   return in_closed(t, t_min, t_max) & in_closed(a, a0, a1) & in_closed(b, b0, b1);
 }
+// Double precision keeps the reference's six comparisons as written (negated, so that a NaN passes them as it does there).
+template <int AXIS>
+RT_DEV bool rect_fast(double a0, double a1, double b0, double b1, double k, const Ray<double>& ray, const RayRcp<double>& ri, double t_min,
+                      double t_max, double& t_out) {
+  return rect_t<double, AXIS>(a0, a1, b0, b1, k, ray, ri, t_min, t_max, t_out);
+}
 
 // The six sides of a box (src/box_struct.rs:22-71) as three slabs: the ray meets the surface where it enters (largest of the
 // per-axis near distances) and where it leaves (smallest far distance), provided enter <= leave; the closest of the two inside
 // [t_min, t_max] is what testing the six rectangles one by one returns.  Side numbering and tie order (a later side wins:
 // x sides over y sides over z sides) follow the reference's list.  `self_side` (>= 0) removes the side the ray starts on.
-RT_DEV bool box_slab_t(const DShape<float>& s, const Ray<float>& ray, const RayInv<float>& ri, float t_min, float t_max, int self_side,
-                       float& t_out, int& side_out) {
-  const float x0 = (s.p[0] - ray.o.x) * ri.inv.x, x1 = (s.p[3] - ray.o.x) * ri.inv.x;
-  const float y0 = (s.p[1] - ray.o.y) * ri.inv.y, y1 = (s.p[4] - ray.o.y) * ri.inv.y;
-  const float z0 = (s.p[2] - ray.o.z) * ri.inv.z, z1 = (s.p[5] - ray.o.z) * ri.inv.z;
-  const float nx = rt_min(x0, x1), fx = rt_max(x0, x1);
-  const float ny = rt_min(y0, y1), fy = rt_max(y0, y1);
-  const float nz = rt_min(z0, z1), fz = rt_max(z0, z1);
-  const float tn = rt_max(rt_max(nx, ny), nz);
-  const float tf = rt_min(rt_min(fx, fy), fz);
+template <class R>
+RT_DEV bool box_slab_t(const DShape<R>& s, const Ray<R>& ray, const RayRcp<R>& ri, R t_min, R t_max, int self_side, R& t_out, int& side_out) {
+  const R x0 = (s.p[0] - ray.o.x) * ri.inv.x, x1 = (s.p[3] - ray.o.x) * ri.inv.x;
+  const R y0 = (s.p[1] - ray.o.y) * ri.inv.y, y1 = (s.p[4] - ray.o.y) * ri.inv.y;
+  const R z0 = (s.p[2] - ray.o.z) * ri.inv.z, z1 = (s.p[5] - ray.o.z) * ri.inv.z;
+  const R nx = rt_min(x0, x1), fx = rt_max(x0, x1);
+  const R ny = rt_min(y0, y1), fy = rt_max(y0, y1);
+  const R nz = rt_min(z0, z1), fz = rt_max(z0, z1);
+  const R tn = rt_max(rt_max(nx, ny), nz);
+  const R tf = rt_min(rt_min(fx, fy), fz);
   // sides: 0 z=hi, 1 z=lo, 2 y=hi, 3 y=lo, 4 x=hi, 5 x=lo; the near plane of an axis is lo when the ray moves up that axis
-  const int px = ray.d.x > 0.0f ? 1 : 0, py = ray.d.y > 0.0f ? 1 : 0, pz = ray.d.z > 0.0f ? 1 : 0;
+  const int px = ray.d.x > (R)0 ? 1 : 0, py = ray.d.y > (R)0 ? 1 : 0, pz = ray.d.z > (R)0 ? 1 : 0;
   const int near_side = nx == tn ? 4 + px : (ny == tn ? 2 + py : pz);
   const int far_side = fx == tf ? 5 - px : (fy == tf ? 3 - py : 1 - pz);
   const bool cross = tn <= tf;
@@ -332,92 +355,97 @@ RT_DEV bool box_slab_t(const DShape<float>& s, const Ray<float>& ray, const RayI
 }
 
 // Entry and exit distances of the line through a box (no range applied); false when the line misses it.
-RT_DEV bool box_slab_span(const DShape<float>& s, const Ray<float>& ray, const RayInv<float>& ri, float& tn, float& tf) {
-  const float x0 = (s.p[0] - ray.o.x) * ri.inv.x, x1 = (s.p[3] - ray.o.x) * ri.inv.x;
-  const float y0 = (s.p[1] - ray.o.y) * ri.inv.y, y1 = (s.p[4] - ray.o.y) * ri.inv.y;
-  const float z0 = (s.p[2] - ray.o.z) * ri.inv.z, z1 = (s.p[5] - ray.o.z) * ri.inv.z;
+template <class R> RT_DEV bool box_slab_span(const DShape<R>& s, const Ray<R>& ray, const RayRcp<R>& ri, R& tn, R& tf) {
+  const R x0 = (s.p[0] - ray.o.x) * ri.inv.x, x1 = (s.p[3] - ray.o.x) * ri.inv.x;
+  const R y0 = (s.p[1] - ray.o.y) * ri.inv.y, y1 = (s.p[4] - ray.o.y) * ri.inv.y;
+  const R z0 = (s.p[2] - ray.o.z) * ri.inv.z, z1 = (s.p[5] - ray.o.z) * ri.inv.z;
   tn = rt_max(rt_max(rt_min(x0, x1), rt_min(y0, y1)), rt_min(z0, z1));
   tf = rt_min(rt_min(rt_max(x0, x1), rt_max(y0, y1)), rt_max(z0, z1));
   return tn <= tf;
 }
 
-// Single precision, scenes of a few leaves: every leaf is tested with the same shrinking t_max - plain rectangles first,
-// grouped by axis, then the other leaves in the order the tree would visit them (among exactly coincident surfaces the last
-// one tested is reported, so at shared edges the order shows).  A box test can only skip leaves the ray does not hit (up to
-// rounding at grazing incidence, which the single-precision tolerance covers), and with incoherent rays every wave visits
-// every entry anyway, so the inner box tests and the per-lane position in the tree are pure overhead here.
-template <class C>
-RT_DEV bool traverse_flat(const SceneView<float, C>& sv, int start, const Ray<float>& ray, float t_min, float t_max, Rec<float>& rec, Stream& media,
-                          Origin org) {
-  const RayInv<float> ri(ray.d);
-  float closest = t_max;
+// Scenes of a few leaves: every leaf is tested with the same shrinking t_max and no box test in between.  A box test can only
+// skip leaves the ray does not hit (up to rounding at grazing incidence), and with incoherent rays every wave visits every entry
+// anyway, so the inner box tests and the per-lane position in the tree are pure overhead here.
+//   Double precision: the leaves in the order the tree visits them, so that among exactly coincident surfaces (a box standing on
+//   the floor) the same one is reported as by the reference's walk; a box is three slabs, and plane distances are
+//   (plane - origin) * (1 / direction) (see RayRcp), so t is within 1 ulp of the reference's quotient.
+//   Single precision: plain rectangles first, grouped by axis, then the other leaves in visiting order.
+template <class R, class C>
+RT_DEV bool traverse_flat(const SceneView<R, C>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
+  const RayRcp<R> ri(ray.d);
+  R closest = t_max;
   int best_leaf = -1, best_side = -1;
   // No box test at all, not even the root's: a ray that starts on a surface starts inside the root box, and camera rays that miss
   // it share their wave with lanes at other bounces, so the early out would never be taken by a whole wave.
   (void)start;
   RT_STAMP_IN(media, 3);
   {
-    const int org_leaf = org.leaf(), org_side = org.side();
-    // plain rectangles, one list per constant axis: one record fetch and a dozen vector instructions each
-    const FlatRect* fr = sv.frect;
-    for (uint32_t k = 0; k < sv.n_frect[0]; ++k, ++fr) {
-      const FlatRect r = load_uniform(fr);
-      float t;
-      const bool ok = rect_fast<0>(r.a0, r.a1, r.b0, r.b1, r.k, ray, ri, t_min, closest, t) & (org_leaf != r.obj);
-      closest = ok ? t : closest; best_leaf = ok ? r.obj : best_leaf; best_side = ok ? -1 : best_side;
-    }
-    for (uint32_t k = 0; k < sv.n_frect[1]; ++k, ++fr) {
-      const FlatRect r = load_uniform(fr);
-      float t;
-      const bool ok = rect_fast<1>(r.a0, r.a1, r.b0, r.b1, r.k, ray, ri, t_min, closest, t) & (org_leaf != r.obj);
-      closest = ok ? t : closest; best_leaf = ok ? r.obj : best_leaf; best_side = ok ? -1 : best_side;
-    }
-    for (uint32_t k = 0; k < sv.n_frect[2]; ++k, ++fr) {
-      const FlatRect r = load_uniform(fr);
-      float t;
-      const bool ok = rect_fast<2>(r.a0, r.a1, r.b0, r.b1, r.k, ray, ri, t_min, closest, t) & (org_leaf != r.obj);
-      closest = ok ? t : closest; best_leaf = ok ? r.obj : best_leaf; best_side = ok ? -1 : best_side;
+    const int org_leaf = Guard<R>::on ? org.leaf() : -1, org_side = org.side();
+    if constexpr (Guard<R>::on) {
+      // plain rectangles, one list per constant axis: one record fetch and a dozen vector instructions each
+      const FlatRect* fr = sv.frect;
+      for (uint32_t k = 0; k < sv.n_frect[0]; ++k, ++fr) {
+        const FlatRect r = load_uniform(fr);
+        R t;
+        const bool ok = rect_fast<0>(r.a0, r.a1, r.b0, r.b1, r.k, ray, ri, t_min, closest, t) & (org_leaf != r.obj);
+        closest = ok ? t : closest; best_leaf = ok ? r.obj : best_leaf; best_side = ok ? -1 : best_side;
+      }
+      for (uint32_t k = 0; k < sv.n_frect[1]; ++k, ++fr) {
+        const FlatRect r = load_uniform(fr);
+        R t;
+        const bool ok = rect_fast<1>(r.a0, r.a1, r.b0, r.b1, r.k, ray, ri, t_min, closest, t) & (org_leaf != r.obj);
+        closest = ok ? t : closest; best_leaf = ok ? r.obj : best_leaf; best_side = ok ? -1 : best_side;
+      }
+      for (uint32_t k = 0; k < sv.n_frect[2]; ++k, ++fr) {
+        const FlatRect r = load_uniform(fr);
+        R t;
+        const bool ok = rect_fast<2>(r.a0, r.a1, r.b0, r.b1, r.k, ray, ri, t_min, closest, t) & (org_leaf != r.obj);
+        closest = ok ? t : closest; best_leaf = ok ? r.obj : best_leaf; best_side = ok ? -1 : best_side;
+      }
     }
     for (uint32_t k = 0; k < sv.n_flat; ++k) {
       const uint32_t word = load_uniform_u32(sv.flat + k);
       const int obj = (int)(word & LEAF_INDEX_MASK);
-      const DShape<float> s = sv.shape(obj);
+      const DShape<R> s = sv.shape(obj);
       const bool self = org_leaf == obj;
-      float t = 0.0f;
+      R t = (R)0;
       int side = -1;
       bool ok = false;
       bool plain = (word & LEAF_SIMPLE) != 0u;
-      Ray<float> local = ray;
-      RayInv<float> rl = ri;
+      Ray<R> local = ray;
+      RayRcp<R> rl = ri;
       if constexpr (C::has(F_XFORM) || C::has(F_MEDIUM)) {
         if (!plain) {
-          const DObject<float> ob = sv.object(obj);
+          const DObject<R> ob = sv.object(obj);
           bool medium = false;
           if constexpr (C::has(F_MEDIUM)) medium = (ob.flags & OBJ_MEDIUM) != 0u;
           if (medium) {
-            if (s.tag == SH_BOX) {
-              // src/constant_medium.rs:41-111 with a box boundary: the first crossing of the whole line is where the ray enters
-              // the three slabs, the first one at least 0.0001 later is where it leaves them; one slab evaluation gives both.
-              Ray<float> moved;
-              to_local(ob, ray, moved, local);
-              if (ob.flags & OBJ_ROTATE_Y) {
-                rl.inv.x = __builtin_amdgcn_rcpf(local.d.x);
-                rl.inv.z = __builtin_amdgcn_rcpf(local.d.z);
-              }
-              float tn, tf;
-              const bool cross = box_slab_span(s, local, rl, tn, tf);
-              float t_after = tn + 0.0001f;
-              if (!(t_after > tn)) t_after = nextafterf(tn, Lim<float>::inf());
-              float t1 = tn, t2 = tf;
+            // src/constant_medium.rs:41-111.  The first crossing of the whole line is where the ray enters the boundary, the
+            // first one at least 0.0001 later is where it leaves it: a box gives both from one slab evaluation, a sphere from
+            // the two roots of its quadratic.
+            Ray<R> moved;
+            to_local(ob, ray, moved, local);
+            if (ob.flags & OBJ_ROTATE_Y) {
+              rl.inv.x = flat_rcp(local.d.x);
+              rl.inv.z = flat_rcp(local.d.z);
+            }
+            R tn = (R)0, tf = (R)0;
+            bool cross = false, spanned = false;
+            if (s.tag == SH_BOX) { cross = box_slab_span(s, local, rl, tn, tf); spanned = true; }
+            if (spanned) {
+              R t_after = tn + (R)0.0001;
+              if (!(t_after > tn)) t_after = next_up(tn);
+              R t1 = tn, t2 = tf;
               bool in = cross & (tf >= t_after);
               if (t1 < t_min) t1 = t_min;
               if (t2 > closest) t2 = closest;
               in = in & !(t1 >= t2);
-              if (t1 < 0.0f) t1 = 0.0f;
+              if (t1 < (R)0) t1 = (R)0;
               if (in) {
-                const float ray_length = length(ray.d);
-                const float distance_inside_boundary = (t2 - t1) * ray_length;
-                const float hit_distance = ob.neg_inv_density * gen_log01(media, (uint32_t)s.obj_id, 0.0f);
+                const R ray_length = length(ray.d);
+                const R distance_inside_boundary = (t2 - t1) * ray_length;
+                const R hit_distance = ob.neg_inv_density * gen_log01(media, medium_slot((uint32_t)s.obj_id, visit_bit(word, 0)), (R)0);
                 if (!(hit_distance > distance_inside_boundary)) {
                   t = t1 + hit_distance / ray_length;
                   side = SIDE_MEDIUM;
@@ -425,14 +453,15 @@ RT_DEV bool traverse_flat(const SceneView<float, C>& sv, int start, const Ray<fl
                 }
               }
             } else {
-              ok = leaf_t<float, C>(sv, word, ray, ri, t_min, closest, media, org, t, side);
+              const RayInv<R> rq(ray.d);
+              ok = leaf_t<R, C>(sv, word, ray, rq, t_min, closest, media, org, t, side, visit_bit(word, 0));
             }
           } else {
-            Ray<float> moved;
+            Ray<R> moved;
             to_local(ob, ray, moved, local);
             if (ob.flags & OBJ_ROTATE_Y) {  // the y component of the direction is unchanged
-              rl.inv.x = __builtin_amdgcn_rcpf(local.d.x);
-              rl.inv.z = __builtin_amdgcn_rcpf(local.d.z);
+              rl.inv.x = flat_rcp(local.d.x);
+              rl.inv.z = flat_rcp(local.d.z);
             }
             plain = true;
           }
@@ -441,7 +470,7 @@ RT_DEV bool traverse_flat(const SceneView<float, C>& sv, int start, const Ray<fl
       if (plain) {
         switch (s.tag) {
           case SH_SPHERE: if constexpr (C::has(F_SPHERE)) {
-            ok = sphere_roots(V3<float>(s.p[0], s.p[1], s.p[2]), local, s.p[3], t_min, closest, t, self);
+            ok = sphere_roots(V3<R>(s.p[0], s.p[1], s.p[2]), local, s.p[3], t_min, closest, t, self);
           } break;
           case SH_MOVING: if constexpr (C::has(F_MOVING)) {
             ok = sphere_roots(moving_center(s, local.time), local, s.p[6], t_min, closest, t, self);
@@ -449,7 +478,7 @@ RT_DEV bool traverse_flat(const SceneView<float, C>& sv, int start, const Ray<fl
           case SH_RECT_XY: if constexpr (C::has(F_RECT)) { ok = rect_fast<2>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], local, rl, t_min, closest, t) & !self; } break;
           case SH_RECT_XZ: if constexpr (C::has(F_RECT)) { ok = rect_fast<1>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], local, rl, t_min, closest, t) & !self; } break;
           case SH_RECT_YZ: if constexpr (C::has(F_RECT)) { ok = rect_fast<0>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], local, rl, t_min, closest, t) & !self; } break;
-          case SH_BOX: if constexpr (C::has(F_BOX)) { ok = box_slab_t(s, local, rl, t_min, closest, self ? org_side : -2, t, side); } break;
+          case SH_BOX: if constexpr (C::has(F_BOX)) { ok = box_slab_t<R>(s, local, rl, t_min, closest, self ? org_side : -2, t, side); } break;
           default: break;
         }
       }
@@ -465,23 +494,25 @@ RT_DEV bool traverse_flat(const SceneView<float, C>& sv, int start, const Ray<fl
     // chain of set_face_normal calls - shape, RotateY (which pairs the rotated normal with the UNrotated-frame direction,
     // src/hittable.rs:236-239), Translate (src/hittable.rs:146-148) - as signs of one vector.
     if (best_side != SIDE_MEDIUM) {
-      const FlatFace f = sv.faces_lane[6 * best_leaf + (best_side < 0 ? 0 : best_side)];
-      const DShape<float>& s = sv.shapes_lane[best_leaf];
+      const FlatFace<R> f = sv.faces_lane[6 * best_leaf + (best_side < 0 ? 0 : best_side)];
+      const DShape<R>& s = sv.shapes_lane[best_leaf];
       const int axis = (int)((f.flags >> 4) & 3u);
-      const V3<float> nw(f.n[0], f.n[1], f.n[2]);
-      V3<float> dl = ray.d;
+      const V3<R> nw(f.n[0], f.n[1], f.n[2]);
+      V3<R> dl = ray.d;
       if (f.flags & OBJ_ROTATE_Y) {
         dl.x = f.cos_theta * ray.d.x - f.sin_theta * ray.d.z;
         dl.z = f.sin_theta * ray.d.x + f.cos_theta * ray.d.z;
       }
-      const float d1 = axis == 0 ? dl.x : axis == 1 ? dl.y : dl.z;
-      bool front = d1 < 0.0f;
-      float sgn = front ? 1.0f : -1.0f;
-      if (f.flags & OBJ_ROTATE_Y) { front = sgn * dot(dl, nw) < 0.0f; sgn = front ? sgn : -sgn; }
-      if (f.flags & OBJ_TRANSLATE) { front = sgn * dot(ray.d, nw) < 0.0f; sgn = front ? sgn : -sgn; }
-      V3<float> p = ray.at(closest);
-      if (!(f.flags & (OBJ_ROTATE_Y | OBJ_TRANSLATE))) {  // an untransformed side: the point lies on its plane exactly
-        p.x = axis == 0 ? f.k : p.x; p.y = axis == 1 ? f.k : p.y; p.z = axis == 2 ? f.k : p.z;
+      const R d1 = axis == 0 ? dl.x : axis == 1 ? dl.y : dl.z;
+      bool front = d1 < (R)0;
+      R sgn = front ? (R)1 : (R)-1;
+      if (f.flags & OBJ_ROTATE_Y) { front = sgn * dot(dl, nw) < (R)0; sgn = front ? sgn : -sgn; }
+      if (f.flags & OBJ_TRANSLATE) { front = sgn * dot(ray.d, nw) < (R)0; sgn = front ? sgn : -sgn; }
+      V3<R> p = ray.at(closest);
+      if constexpr (Guard<R>::on) {
+        if (!(f.flags & (OBJ_ROTATE_Y | OBJ_TRANSLATE))) {  // an untransformed side: the point lies on its plane exactly
+          p.x = axis == 0 ? f.k : p.x; p.y = axis == 1 ? f.k : p.y; p.z = axis == 2 ? f.k : p.z;
+        }
       }
       rec.t = closest; rec.p = p; rec.n = sgn * nw; rec.front = front;
       rec.mat = s.material; rec.obj = s.obj_id; rec.sub = s.sub_id;
@@ -490,7 +521,7 @@ RT_DEV bool traverse_flat(const SceneView<float, C>& sv, int start, const Ray<fl
       return true;
     }
   }
-  finalize_hit<float, C>(sv, ray, closest, best_leaf, best_side, rec);
+  finalize_hit<R, C>(sv, ray, closest, best_leaf, best_side, rec);
   RT_STAMP_IN(media, 5);
   return true;
 }
@@ -527,31 +558,75 @@ RT_DEV bool traverse_lane_deferred(const SceneView<float, C>& sv, int start, con
         const LaneBoxTest<float> lbox(local);
         RayInv<float> rl(local.d);
         rl.inv = lbox.inv;
-        int j = ob.sub_root;
-        while (j >= 0) {
-          DLink<float> nl = sv.link(j);
-          while (!(nl.hit & LEAF_FLAG)) {
-            j = lbox.hit(nl, local, t_min, closest) ? (int)nl.hit : nl.miss;
+        // closest candidate of the nested tree inside [lo, hi] (BVHNode::hit on the holder's tree, src/bvh.rs:108-119)
+        auto nested_closest = [&](float lo, float hi, Origin from, float& t_best, int& leaf_best, int& side_best) {
+          bool found = false;
+          int j = ob.sub_root;
+          while (j >= 0) {
+            DLink<float> nl = sv.link(j);
+            while (!(nl.hit & LEAF_FLAG)) {
+              j = lbox.hit(nl, local, lo, hi) ? (int)nl.hit : nl.miss;
+              if (j < 0) break;
+              nl = sv.link(j);
+            }
             if (j < 0) break;
-            nl = sv.link(j);
+            float t;
+            int side;
+            if (leaf_t<float, C>(sv, nl.hit, local, rl, lo, hi, media, from, t, side, visit_bit(lk.hit, 0) | visit_bit(nl.hit, 1))) {
+              hi = t;
+              t_best = t;
+              leaf_best = (int)(nl.hit & LEAF_INDEX_MASK);
+              side_best = side;
+              found = true;
+            }
+            j = nl.miss;
           }
-          if (j < 0) break;
-          float t;
-          int side;
-          if (leaf_t<float, C>(sv, nl.hit, local, rl, t_min, closest, media, org, t, side)) {
+          return found;
+        };
+        bool medium = false;
+        if constexpr (C::has(F_MEDIUM)) medium = (ob.flags & OBJ_MEDIUM) != 0u;
+        if (medium) {
+          // ConstantMedium whose boundary is the nested tree (src/constant_medium.rs:41-111): first crossing of the whole line,
+          // first crossing at least 0.0001 later, then the free-path draw of the holder
+          const float inf = Lim<float>::inf();
+          float t1 = 0.0f, t2 = 0.0f;
+          int l_unused = -1, s_unused = -1;
+          if (nested_closest(-inf, inf, Origin(), t1, l_unused, s_unused)) {
+            float t_after = t1 + 0.0001f;
+            if (!(t_after > t1)) t_after = nextafterf(t1, inf);
+            if (nested_closest(t_after, inf, Origin(), t2, l_unused, s_unused)) {
+              if (t1 < t_min) t1 = t_min;
+              if (t2 > closest) t2 = closest;
+              if (!(t1 >= t2)) {
+                if (t1 < 0.0f) t1 = 0.0f;
+                const float ray_length = length(ray.d);
+                const float distance_inside_boundary = (t2 - t1) * ray_length;
+                const float hit_distance = ob.neg_inv_density * gen_log01(media, medium_slot((uint32_t)sv.shape(obj).obj_id, visit_bit(lk.hit, 0)), 0.0f);
+                if (!(hit_distance > distance_inside_boundary)) {
+                  closest = t1 + hit_distance / ray_length;
+                  best_leaf = obj;
+                  best_side = SIDE_MEDIUM;
+                  best_holder = -1;
+                }
+              }
+            }
+          }
+        } else {
+          float t = 0.0f;
+          int leaf = -1, side = -1;
+          if (nested_closest(t_min, closest, org, t, leaf, side)) {
             closest = t;
-            best_leaf = (int)(nl.hit & LEAF_INDEX_MASK);
+            best_leaf = leaf;
             best_side = side;
             best_holder = obj;
           }
-          j = nl.miss;
         }
       }
     }
     if (!nested) {
       float t;
       int side;
-      if (leaf_t<float, C>(sv, lk.hit, ray, ri, t_min, closest, media, org, t, side)) {
+      if (leaf_t<float, C>(sv, lk.hit, ray, ri, t_min, closest, media, org, t, side, visit_bit(lk.hit, 0))) {
         closest = t;
         best_leaf = obj;
         best_side = side;
@@ -591,9 +666,7 @@ RT_DEV bool traverse_lane_deferred(const SceneView<float, C>& sv, int start, con
 template <class R, class C>
 RT_DEV bool closest_hit(const SceneView<R, C>& sv, int root, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
   if constexpr (C::walk == WALK_UNIFORM) {
-    if constexpr (sizeof(R) == sizeof(float)) {
-      if (sv.flat_mode != 0u) return traverse_flat<C>(sv, root, ray, t_min, t_max, rec, media, org);
-    }
+    if (sv.flat_mode != 0u) return traverse_flat<R, C>(sv, root, ray, t_min, t_max, rec, media, org);
     return traverse_uniform<R, C>(sv, root, ray, t_min, t_max, rec, media, org);
   } else {
     if constexpr (sizeof(R) == sizeof(float)) return traverse_lane_deferred<C>(sv, root, ray, t_min, t_max, rec, media, org);

@@ -39,30 +39,41 @@ template <> inline float round_up<float>(double x) {
 }
 
 
-template <class R>
-int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink>& links, int root_link, const std::vector<int>& sub_root_of_object,
-                int preset, SceneImage<R>& im) {
-  BlobLayout lay{};
+// Byte offsets of the blob's sections from the counts in `lay` (every section 16-byte aligned).
+template <class R> void layout_sections(BlobLayout& lay) {
   uint32_t off = 0;
-  lay.n_links = (uint32_t)links.size();
-  lay.n_objects = (uint32_t)s.n_objects;
-  lay.n_materials = (uint32_t)s.n_materials;
-  lay.n_textures = (uint32_t)std::max(1, s.n_textures);
-  lay.n_perlins = (uint32_t)s.n_perlins;
   lay.links_off = off; off = align16(off + lay.n_links * (uint32_t)sizeof(DLink<R>));
   lay.shapes_off = off; off = align16(off + lay.n_objects * (uint32_t)sizeof(DShape<R>));
   lay.objects_off = off; off = align16(off + lay.n_objects * (uint32_t)sizeof(DObject<R>));
   lay.materials_off = off; off = align16(off + lay.n_materials * (uint32_t)sizeof(DMaterial<R>));
   lay.textures_off = off; off = align16(off + lay.n_textures * (uint32_t)sizeof(DTexture<R>));
   lay.perlins_off = off; off = align16(off + lay.n_perlins * (uint32_t)sizeof(DPerlin<R>));
+  lay.flat_off = off; off = align16(off + (uint32_t)(kFlatMaxLeaves * sizeof(uint32_t)));
+  lay.frect_off = off; off = align16(off + (uint32_t)(kFlatMaxLeaves * sizeof(FlatRect)));
+  lay.faces_off = off;
+  if (lay.flat_mode) off = align16(off + (uint32_t)(6u * lay.n_objects * sizeof(FlatFace<R>)));
+  lay.total_bytes = off;
+}
+
+template <class R>
+int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink>& links, int root_link, const std::vector<int>& sub_root_of_object,
+                int preset, SceneImage<R>& im) {
+  BlobLayout lay{};
+  lay.n_links = (uint32_t)links.size();
+  lay.n_objects = (uint32_t)s.n_objects;
+  lay.n_materials = (uint32_t)s.n_materials;
+  lay.n_textures = (uint32_t)std::max(1, s.n_textures);
+  lay.n_perlins = (uint32_t)s.n_perlins;
   // leaf words in visiting order (the small-scene presets store their links in that order)
   std::vector<uint32_t> flat;
   const bool uniform_preset = preset == PRESET_BOXES || preset == PRESET_SMOKE || preset == PRESET_SPHERES;
-  if (uniform_preset && sizeof(R) == sizeof(float) && !getenv("RTAMD_NO_FLAT")) {
+  constexpr bool single = sizeof(R) == sizeof(float);
+  if (uniform_preset && !getenv("RTAMD_NO_FLAT") && !(!single && getenv("RTAMD_NO_FLAT_F64"))) {
     for (const TmpLink& l : links)
       if (l.hit & LEAF_FLAG) flat.push_back(l.hit);
     // a tree may hold the same object more than once (a one-object tree tests it twice, src/bvh.rs:38): testing it again gives
-    // the same distance, which the closed range accepts again, so only its last visit is kept
+    // the same distance, which the closed range accepts again, so only its last visit is kept (the second visit of a medium
+    // carries LEAF_SECOND, is a different word, and stays)
     for (size_t k = 0; k < flat.size();) {
       bool again = false;
       for (size_t m = k + 1; m < flat.size(); ++m) again = again || flat[m] == flat[k];
@@ -70,7 +81,7 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
     }
     if (flat.size() > kFlatMaxLeaves) flat.clear();
   }
-  // plain rectangles leave the list of leaf words for per-axis lists of ready-made records
+  // single precision: plain rectangles leave the list of leaf words for per-axis lists of ready-made records
   std::vector<FlatRect> frects[3];
   std::vector<uint32_t> others;
   for (uint32_t word : flat) {
@@ -78,7 +89,7 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
     const rt_object& o = s.objects[obj];
     const rt_shape& sh = s.shapes[o.geom];
     const int axis = sh.tag == RT_SHAPE_RECT_YZ ? 0 : sh.tag == RT_SHAPE_RECT_XZ ? 1 : sh.tag == RT_SHAPE_RECT_XY ? 2 : -1;
-    if ((word & LEAF_SIMPLE) && axis >= 0 && !getenv("RTAMD_NO_FLAT_RECTS")) {
+    if (single && (word & LEAF_SIMPLE) && axis >= 0 && !getenv("RTAMD_NO_FLAT_RECTS")) {
       FlatRect r{};
       r.a0 = (float)sh.p[0]; r.a1 = (float)sh.p[1]; r.b0 = (float)sh.p[2]; r.b1 = (float)sh.p[3]; r.k = (float)sh.p[4];
       r.obj = obj;
@@ -88,16 +99,12 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
     }
   }
   lay.flat_mode = flat.empty() ? 0u : 1u;
-  lay.flat_off = off; off = align16(off + (uint32_t)(kFlatMaxLeaves * sizeof(uint32_t)));
   lay.n_flat = (uint32_t)others.size();
-  lay.frect_off = off; off = align16(off + (uint32_t)(kFlatMaxLeaves * sizeof(FlatRect)));
   for (int k = 0; k < 3; ++k) lay.n_frect[k] = (uint32_t)frects[k].size();
-  lay.faces_off = off;
-  if (lay.flat_mode) off = align16(off + (uint32_t)(6u * lay.n_objects * sizeof(FlatFace)));
-  lay.total_bytes = off;
-  std::vector<uint8_t> blob(off, 0);
+  layout_sections<R>(lay);
+  std::vector<uint8_t> blob(lay.total_bytes, 0);
   if (lay.flat_mode) {
-    FlatFace* F = reinterpret_cast<FlatFace*>(blob.data() + lay.faces_off);
+    FlatFace<R>* F = reinterpret_cast<FlatFace<R>*>(blob.data() + lay.faces_off);
     for (int i = 0; i < s.n_objects; ++i) {
       const rt_object& o = s.objects[i];
       if (o.flags & RT_OBJ_SUB_BVH) continue;
@@ -105,18 +112,18 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
       const bool box = sh.tag == RT_SHAPE_BOX;
       if (!box && sh.tag != RT_SHAPE_RECT_XY && sh.tag != RT_SHAPE_RECT_XZ && sh.tag != RT_SHAPE_RECT_YZ) continue;
       const bool rot = (o.flags & RT_OBJ_ROTATE_Y) != 0;
-      const float cs = rot ? (float)o.cos_theta : 1.0f, sn = rot ? (float)o.sin_theta : 0.0f;
+      const R cs = rot ? (R)o.cos_theta : (R)1, sn = rot ? (R)o.sin_theta : (R)0;
       for (int side = 0; side < (box ? 6 : 1); ++side) {
         // box sides: 0 z=hi, 1 z=lo, 2 y=hi, 3 y=lo, 4 x=hi, 5 x=lo (the reference's list order, src/box_struct.rs:22-71)
         const int axis = box ? (side < 2 ? 2 : side < 4 ? 1 : 0) : (sh.tag == RT_SHAPE_RECT_XY ? 2 : sh.tag == RT_SHAPE_RECT_XZ ? 1 : 0);
         static const int box_k[6] = {5, 2, 4, 1, 3, 0};
-        FlatFace& f = F[6 * i + side];
-        f.n[0] = axis == 0 ? cs : axis == 2 ? sn : 0.0f;   // RotateY of the axis vector (src/hittable.rs:229-239)
-        f.n[1] = axis == 1 ? 1.0f : 0.0f;
-        f.n[2] = axis == 0 ? -sn : axis == 2 ? cs : 0.0f;
+        FlatFace<R>& f = F[6 * i + side];
+        f.n[0] = axis == 0 ? cs : axis == 2 ? sn : (R)0;   // RotateY of the axis vector (src/hittable.rs:229-239)
+        f.n[1] = axis == 1 ? (R)1 : (R)0;
+        f.n[2] = axis == 0 ? -sn : axis == 2 ? cs : (R)0;
         f.flags = (o.flags & 15u) | ((uint32_t)axis << 4);
         f.cos_theta = cs; f.sin_theta = sn;
-        f.k = (float)(box ? sh.p[box_k[side]] : sh.p[4]);
+        f.k = (R)(box ? sh.p[box_k[side]] : sh.p[4]);
       }
     }
   }
@@ -476,6 +483,7 @@ template <class R> int resolve_impl(rt_context* c, const void* accum_dev, size_t
 }
 
 #define RTI_INSTANTIATE(R)                                                                                                                   \
+  template void layout_sections<R>(BlobLayout&);                                                                                        \
   template int build_image<R>(rt_context*, const rt_scene_desc&, const std::vector<TmpLink>&, int, const std::vector<int>&, int, SceneImage<R>&); \
   template int render_accum_impl<R>(rt_context*, const rt_render_params&, void*, rt_stats*);                                                \
   template int trace_batch_impl<R>(rt_context*, const rt_ray*, size_t, rt_hit*, uint64_t, bool);                                                  \

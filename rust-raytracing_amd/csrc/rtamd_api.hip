@@ -70,6 +70,8 @@ struct LinkBuilder {
       left_first = child(nd.left, next, depth + 1, tree);
     } else {
       right_first = child(nd.right, next, depth + 1, tree);
+      // a medium in a one-object node: its second visit draws a random number of its own (src/constant_medium.rs:91)
+      if (nd.left < 0 && nd.left == nd.right && right_first >= 0) links[(size_t)right_first].hit |= LEAF_SECOND;
       left_first = child(nd.left, right_first, depth + 1, tree);
     }
     TmpLink& l = links[me];
@@ -88,7 +90,7 @@ int validate(const rt_scene_desc& s, std::string& err) {
   if (s.n_textures > 0 && !s.textures) return bad("textures pointer is NULL");
   if (s.n_perlins > 0 && !s.perlins) return bad("perlins pointer is NULL");
   if (s.n_images > 0 && !s.images) return bad("images pointer is NULL");
-  if ((uint32_t)s.n_objects > LEAF_INDEX_MASK) return bad("too many objects");
+  if ((uint32_t)s.n_objects > LEAF_INDEX_MASK) return bad("too many objects (at most 2^28 - 1)");
   if (s.root_node < 0 || s.root_node >= s.n_nodes) return bad("root_node out of range");
   for (int i = 0; i < s.n_textures; ++i) {
     const rt_texture& t = s.textures[i];
@@ -238,7 +240,13 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   }
   if (s->background.kind == RT_BG_GRADIENT) feat |= F_GRADIENT;
   const char* force = std::getenv("RTAMD_FORCE_GENERIC");
-  const bool small = lb.links.size() <= kUniformMaxLinks && !has_nested && !(force && force[0] == '1');
+  // The small-scene presets stage the whole image in LDS: it has to fit there in both precisions (a Perlin table alone is 11 KiB
+  // in double precision), otherwise the scene takes a per-lane preset, which falls back to staging the top of the tree only.
+  BlobLayout projected{};
+  projected.n_links = (uint32_t)lb.links.size(); projected.n_objects = (uint32_t)s->n_objects; projected.n_materials = (uint32_t)s->n_materials;
+  projected.n_textures = (uint32_t)std::max(1, s->n_textures); projected.n_perlins = (uint32_t)s->n_perlins; projected.flat_mode = 1u;
+  layout_sections<double>(projected);
+  const bool small = lb.links.size() <= kUniformMaxLinks && !has_nested && !(force && force[0] == '1') && projected.total_bytes <= kLdsAllMax;
   int preset = PRESET_ALL_LDS;  // build_image demotes to PRESET_ALL_TOP when the image does not fit in LDS
   if (small && (feat & ~P_BOXES) == 0) preset = PRESET_BOXES;
   else if (small && (feat & ~P_SMOKE) == 0) preset = PRESET_SMOKE;
@@ -308,13 +316,16 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
       dissolved[(size_t)i] = 1;
       for (int ch : children) {
         rt_object& o = objects32[(size_t)ch];
-        // A sphere under RotateY / Translate is the sphere around the moved centre: same t, same point, same normal.  Only the
-        // front_face flag can differ, at grazing incidence, through RotateY's mixed-frame set_face_normal (src/hittable.rs:236-239)
-        // - it is read by Dielectric alone - and (u, v) turn with the sphere, so those materials keep the wrappers.
+        // A sphere under [Translate(] RotateY is the sphere around the moved centre: same t, same point.  Translate, the outermost
+        // wrapper, ends with set_face_normal against the world direction (src/hittable.rs:146-148), which undoes whatever
+        // RotateY's mixed-frame call (src/hittable.rs:236-239) did to the normal; only the front_face flag can then differ, at
+        // grazing incidence - it is read by Dielectric alone - and (u, v) turn with the sphere, so those materials keep the
+        // wrappers.  Under a RotateY without a Translate the mixed-frame call decides the normal itself: wrappers kept.
         const rt_shape& sh = s->shapes[o.geom];
         const rt_material& m = s->materials[sh.material];
         const bool uv_free = m.texture < 0 || m.texture >= s->n_textures || s->textures[m.texture].tag != RT_TEX_IMAGE;
-        if (sh.tag == RT_SHAPE_SPHERE && m.tag != RT_MAT_DIELECTRIC && uv_free) {
+        const bool normal_restored = (holder.flags & RT_OBJ_TRANSLATE) != 0 || !(holder.flags & RT_OBJ_ROTATE_Y);
+        if (sh.tag == RT_SHAPE_SPHERE && m.tag != RT_MAT_DIELECTRIC && uv_free && normal_restored) {
           shapes32.push_back(sh);
           rt_shape& moved = shapes32.back();
           const bool rot = (holder.flags & RT_OBJ_ROTATE_Y) != 0, tr = (holder.flags & RT_OBJ_TRANSLATE) != 0;
