@@ -88,22 +88,34 @@ inline void philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 enum Stage : uint32_t { STAGE_CAMERA = 0, STAGE_MEDIA = 1, STAGE_SCATTER = 2 };
 
 // One random stream = Philox keyed by (pixel, sample); counter =
-// (block, bounce | stage<<16 | half<<20, seed_lo, seed_hi).  Draws are ADDRESSED:
-// draw slot s is the 64-bit word  H[s&3] << 32 | L[s&3]  where H is block s>>2
-// with half = 0 and L the same block with half = 1.  (A single-precision
+// (block, bounce | stage<<16, seed_lo, seed_hi).  Draws are ADDRESSED:
+// draw slot s is the 64-bit word  H[s&3] << 32 | L[s&3]  where H is Philox block
+// s>>2 and L[j] = low_mix(H[j], H[(j+1)&3]) * 0x846CA68B.  (A single-precision
 // evaluation only ever needs H.)  Slot assignment per stage:
 //   CAMERA   slot 0 = pixel jitter u, 1 = jitter v, 2 = shutter time;
 //            lens-disk candidate c uses slots 4(1+c), 4(1+c)+1
 //   SCATTER  unit-sphere candidate c (Lambertian, Metal fuzz, Isotropic) takes
 //            two words (w0, w1) of H block c>>1 - words 0,1 for even c, 2,3 for
-//            odd c - cut into three 21-bit fields, and words 0..2 of L block c
-//            for the 31 low bits of each coordinate (52-bit mantissas, the
-//            resolution of rand's gen_range); Dielectric's one uniform is slot 0
-//   MEDIA    the free-path draw of ConstantMedium object k is slot k (one
-//            draw per object and ray, whatever order the tree visits them in)
+//            odd c - cut into three 21-bit fields, and the three words
+//            low3(w0, w1) for the 31 low bits of each coordinate (52-bit
+//            mantissas, the resolution of rand's gen_range); Dielectric's one
+//            uniform is slot 0
+//   MEDIA    the free-path draw of ConstantMedium object k is slot k, plus the
+//            visit bits of HitCtx (one draw per object, call and ray, whatever
+//            order the tree visits objects in)
 // The rejection loops of vec3.rs:81-88,103-111 therefore read "the first
 // candidate c = 0, 1, 2, ... inside the unit ball / disk", which is what the
 // sequential loop computes.
+// Bits of a draw below those Philox supplies: a multiplicative hash of the Philox words (they only place a value inside an
+// interval of 2^-32, or 2^-21 for a unit-ball coordinate, of its range).
+inline uint32_t low_mix(uint32_t a, uint32_t b) {
+  uint32_t m = (a ^ ((b << 16) | (b >> 16))) * 0x7FEB352Du;
+  return m ^ (m >> 15);
+}
+inline void low3(uint32_t w0, uint32_t w1, uint32_t l[3]) {  // low words of the three coordinates of unit-ball candidate (w0, w1)
+  const uint32_t m = low_mix(w0, w1);
+  l[0] = m * 0x846CA68Bu; l[1] = (m + w1) * 0x9E3779B1u; l[2] = (m ^ w0) * 0x85EBCA77u;
+}
 struct Stream {
   uint32_t key[2];
   uint32_t c1, c2, c3;
@@ -118,17 +130,12 @@ struct Stream {
     uint32_t c[4] = {b, c1, c2, c3};
     philox4x32(c, key, out);
   }
-  void lo_block(uint32_t b, uint32_t out[4]) const {
-    uint32_t c[4] = {b, c1 | (1u << 20), c2, c3};
-    philox4x32(c, key, out);
-  }
   uint64_t word(uint32_t slot) {
     uint32_t b = slot >> 2, j = slot & 3u;
     if (b != cached) {
       uint32_t ch[4] = {b, c1, c2, c3};
-      uint32_t cl[4] = {b, c1 | (1u << 20), c2, c3};
       philox4x32(ch, key, hi);
-      philox4x32(cl, key, lo);
+      for (int k = 0; k < 4; ++k) lo[k] = low_mix(hi[k], hi[(k + 1) & 3]) * 0x846CA68Bu;
       cached = b;
     }
     ++g_cnt.rng_words;
@@ -203,9 +210,9 @@ template <class R> inline V3<R> random_in_unit_sphere(Stream& s) {  // vec3.rs:8
   uint32_t h[4] = {0, 0, 0, 0}, l[4];
   for (uint32_t c = 0;; ++c) {
     if ((c & 1u) == 0) s.hi_block(c >> 1, h);
-    s.lo_block(c, l);
     g_cnt.rng_words += 3;
     uint32_t w0 = (c & 1u) ? h[2] : h[0], w1 = (c & 1u) ? h[3] : h[1];
+    low3(w0, w1, l);
     uint32_t xi = w0 >> 11, yi = ((w0 & 0x7FFu) << 10) | (w1 >> 22), zi = (w1 >> 1) & 0x1FFFFFu;
     V3<R> p(coord_of(xi, l[0] >> 1, (R)0), coord_of(yi, l[1] >> 1, (R)0), coord_of(zi, l[2] >> 1, (R)0));
     if (p.length_squared() < (R)1) return p;

@@ -35,7 +35,7 @@ constexpr uint32_t kLdsTopMax = 32u * 1024u;  // otherwise stage this many bytes
 constexpr uint64_t kTargetPathsPerPass = 64ull << 20;
 constexpr uint32_t kMaxDepth = 4096;
 constexpr uint32_t kRayCountWords = 16 + 8 * 4 * 4096;  // ray counter, then 8 diagnostic words per wave of up to 4096 workgroups
-constexpr uint32_t kFlatMaxLeaves = 16;  // single precision: scenes with at most this many leaves test every leaf, in tree order, without box tests
+using rtd::kFlatMaxLeaves;  // scenes with at most this many leaves take the small-scene presets: every leaf tested, in tree order, no box tests
 constexpr uint32_t kSegments = 64;  // queue segments (a multiple of the 8 XCDs; at most the workgroup size)
 constexpr uint32_t kCounterWords = (kMaxDepth + 2) * kSegments * 11;  // per bounce and segment: queue count, 2 chunk cursors, 8 class counts
 

@@ -39,6 +39,22 @@ RT_DEV double rt_acos(double x) { return acos(x); }
 RT_DEV float rt_atan2(float y, float x) { return atan2f(y, x); }
 RT_DEV double rt_atan2(double y, double x) { return atan2(y, x); }
 
+// 1/x in double precision from the hardware estimate (about 26 bits) and two Newton steps: on gfx950 the result is the IEEE
+// quotient 1.0/x for every finite non-zero x tried (2^20 random arguments, tools/rcp_probe.hip), at half the instructions of the
+// division sequence.  Zero and infinite arguments keep the estimate's own answer (inf / 0), as the division would give.
+RT_DEV double rcp_refined(double x) {
+  const double r0 = __builtin_amdgcn_rcp(x);
+  const double r1 = __builtin_fma(__builtin_fma(-x, r0, 1.0), r0, r0);
+  const double r2 = __builtin_fma(__builtin_fma(-x, r1, 1.0), r1, r1);
+  return __builtin_isfinite(r0) && r0 != 0.0 ? r2 : r0;
+}
+// 1/sqrt(x), hardware estimate and two Newton steps: within 2 ulp (same probe).
+RT_DEV double rsq_refined(double x) {
+  const double s0 = __builtin_amdgcn_rsq(x);
+  const double s1 = __builtin_fma(s0, __builtin_fma(-x * s0, 0.5 * s0, 0.5), s0);
+  return __builtin_fma(s1, __builtin_fma(-x * s1, 0.5 * s1, 0.5), s1);
+}
+
 template <class R> struct V3 {
   R x, y, z;
   RT_HD V3() : x(0), y(0), z(0) {}
@@ -95,12 +111,20 @@ RT_DEV void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
 
 enum : uint32_t { STAGE_CAMERA = 0, STAGE_MEDIA = 1, STAGE_SCATTER = 2 };
 
+// The bits of a draw below the 32 (or 21) that Philox supplies come from a multiplicative hash of the Philox words themselves:
+// they place a value inside an interval of 2^-32 (2^-21 for a unit-ball coordinate) of its range, where all that matters is
+// that they are spread evenly, and a second Philox block per draw costs a tenth of the double-precision frame time.
+RT_DEV uint32_t low_mix(uint32_t a, uint32_t b) {
+  uint32_t m = (a ^ ((b << 16) | (b >> 16))) * 0x7FEB352Du;
+  return m ^ (m >> 15);
+}
+
 // One stream per (pixel, sample, bounce, stage): key = (pixel, sample), counter = (block, bounce | stage << 16 | half << 20,
 // seed_lo, seed_hi).  Draws are addressed, not consumed in sequence: draw slot s is the 64-bit word H[s & 3] << 32 | L[s & 3],
-// H = block s >> 2 with half = 0, L = the same block with half = 1.  Slots by stage:
+// H = Philox block s >> 2, L[j] = low_mix(H[j], H[(j + 1) & 3]) * 0x846CA68B.  Slots by stage:
 //   CAMERA   0 = pixel jitter u, 1 = jitter v, 2 = shutter time; lens-disk candidate c = slots 4(1+c), 4(1+c)+1
-//   SCATTER  unit-sphere candidate c = two words of H block c >> 1 (words 0,1 for even c, 2,3 for odd c) cut into three 21-bit
-//            fields + the top 31 bits of words 0..2 of L block c (52-bit mantissas); the dielectric's uniform = slot 0
+//   SCATTER  unit-sphere candidate c = two words (w0, w1) of H block c >> 1 (words 0,1 for even c, 2,3 for odd c) cut into three
+//            21-bit fields + the top 31 bits of the three words low3(w0, w1) (52-bit mantissas); the dielectric's uniform = slot 0
 //   MEDIA    the free-path draw of ConstantMedium object k = slot k (independent of the order the tree visits objects in)
 // A rejection loop reads "the first candidate c = 0, 1, 2, ... that is accepted" (src/vec3.rs:81-88,103-111).
 // The float build uses the top 24 / 23 bits of a word, so it needs H only and it sees the same numbers, rounded, as the double build.
@@ -113,7 +137,11 @@ struct Stream {
   RT_DEV Stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t stage)
       : k0(pixel), k1(sample), c1(bounce | (stage << 16)), c2((uint32_t)seed), c3((uint32_t)(seed >> 32)) {}
   RT_DEV void hi(uint32_t block, uint32_t h[4]) const { philox4x32(block, c1, c2, c3, k0, k1, h[0], h[1], h[2], h[3]); }
-  RT_DEV void lo(uint32_t block, uint32_t l[4]) const { philox4x32(block, c1 | (1u << 20), c2, c3, k0, k1, l[0], l[1], l[2], l[3]); }
+  // Low halves of the four draw words of a block whose high halves are h (see low_mix).
+  RT_DEV static void lo_of(const uint32_t h[4], uint32_t l[4]) {
+    l[0] = low_mix(h[0], h[1]) * 0x846CA68Bu; l[1] = low_mix(h[1], h[2]) * 0x846CA68Bu;
+    l[2] = low_mix(h[2], h[3]) * 0x846CA68Bu; l[3] = low_mix(h[3], h[0]) * 0x846CA68Bu;
+  }
   // where a rejection loop starts reading candidate blocks, and whether it has to stop before block b (never, for a plain stream)
   RT_DEV uint32_t first_block() const { return 0u; }
   RT_DEV bool out_of_turn(uint32_t) const { return false; }
@@ -169,7 +197,7 @@ template <> struct Block<float> {
 };
 template <> struct Block<double> {
   uint32_t h[4], l[4];
-  template <class S> RT_DEV Block(const S& s, uint32_t b) { s.hi(b, h); s.lo(b, l); }
+  template <class S> RT_DEV Block(const S& s, uint32_t b) { s.hi(b, h); Stream::lo_of(h, l); }
   RT_DEV double u01(int j) const { return u01_of(h[j], l[j], 0.0); }
   RT_DEV double range(int j, double lo, double hi) const { return range_of<double>(h[j], l[j], lo, hi); }
 };
@@ -179,7 +207,7 @@ template <> struct Block<double> {
 RT_DEV uint64_t word_at(const Stream& s, uint32_t slot) {
   uint32_t h[4], l[4];
   s.hi(slot >> 2, h);
-  s.lo(slot >> 2, l);
+  Stream::lo_of(h, l);
   uint32_t j = slot & 3u;
   uint32_t hj = j == 0 ? h[0] : j == 1 ? h[1] : j == 2 ? h[2] : h[3];
   uint32_t lj = j == 0 ? l[0] : j == 1 ? l[1] : j == 2 ? l[2] : l[3];
@@ -200,6 +228,10 @@ RT_DEV float gen_log01(const Stream& s, uint32_t slot, float) {
 // src/vec3.rs:81-88: first candidate (three draws in [-1,1)) inside the unit ball; candidate c is block c of the stream.
 // src/vec3.rs:81-88: first candidate (a point of [-1,1)^3) inside the unit ball.  One Philox block of high halves serves two
 // candidates: its words (0,1) and (2,3) are each cut into three 21-bit coordinates.
+RT_DEV void low3(uint32_t w0, uint32_t w1, uint32_t l[3]) {  // low words of the three coordinates of candidate (w0, w1)
+  const uint32_t m = low_mix(w0, w1);
+  l[0] = m * 0x846CA68Bu; l[1] = (m + w1) * 0x9E3779B1u; l[2] = (m ^ w0) * 0x85EBCA77u;
+}
 RT_DEV void fields21(uint32_t w0, uint32_t w1, uint32_t& xi, uint32_t& yi, uint32_t& zi) {
   xi = w0 >> 11; yi = ((w0 & 0x7FFu) << 10) | (w1 >> 22); zi = (w1 >> 1) & 0x1FFFFFu;
 }
@@ -227,7 +259,7 @@ template <class S> RT_DEV V3<float> random_in_unit_sphere(const S& s, float) {
   }
 }
 // Double build: the high fields alone decide all but a sliver of candidates (the low fields move a coordinate by less than
-// 2^-20, the squared length by less than 5.8e-6), so the low block is fetched once, for the candidate that passes that test.
+// 2^-20, the squared length by less than 5.8e-6), so the low words are formed once, for the candidate that passes that test.
 template <class S> RT_DEV V3<double> random_in_unit_sphere(const S& s, double) {
   uint32_t c = 2u * s.first_block();
   uint32_t h[4] = {0u, 0u, 0u, 0u};
@@ -242,8 +274,8 @@ template <class S> RT_DEV V3<double> random_in_unit_sphere(const S& s, double) {
       w1 = (c & 1u) ? h[3] : h[1];
       if (length_squared(point_of<double>(w0, w1, 0u, 0u, 0u)) < 1.0 + 6e-6) break;
     }
-    uint32_t l[4];
-    s.lo(c, l);
+    uint32_t l[3];
+    low3(w0, w1, l);
     V3<double> p = point_of<double>(w0, w1, l[0], l[1], l[2]);
     if (length_squared(p) < 1.0) return p;
     ++c;
@@ -251,12 +283,17 @@ template <class S> RT_DEV V3<double> random_in_unit_sphere(const S& s, double) {
 }
 template <class R, class S> RT_DEV V3<R> random_in_unit_sphere(const S& s) { return random_in_unit_sphere(s, (R)0); }
 // src/vec3.rs:90-92.  Single precision scales by the hardware reciprocal square root (1 ulp) instead of sqrt then divide.
-template <class S> RT_DEV V3<double> random_unit_vector(const S& s, double) { return unit_vector(random_in_unit_sphere<double>(s)); }
-template <class S> RT_DEV V3<float> random_unit_vector(const S& s, float) {
+// RELAXED (double precision, small-scene presets): the refined reciprocal square root (2 ulp) instead of sqrt then divide.
+template <bool RELAXED, class S> RT_DEV V3<double> random_unit_vector(const S& s, double) {
+  const V3<double> p = random_in_unit_sphere<double>(s);
+  if constexpr (RELAXED) return rsq_refined(length_squared(p)) * p;
+  else return unit_vector(p);
+}
+template <bool RELAXED, class S> RT_DEV V3<float> random_unit_vector(const S& s, float) {
   V3<float> p = random_in_unit_sphere<float>(s);
   return __builtin_amdgcn_rsqf(length_squared(p)) * p;
 }
-template <class R, class S> RT_DEV V3<R> random_unit_vector(const S& s) { return random_unit_vector(s, (R)0); }
+template <class R, bool RELAXED, class S> RT_DEV V3<R> random_unit_vector(const S& s) { return random_unit_vector<RELAXED>(s, (R)0); }
 // src/vec3.rs:103-111 on the camera stream: candidate c is block 1 + c.
 template <class R, class S> RT_DEV V3<R> random_in_unit_disk(const S& s) {
   for (uint32_t c = 0;; ++c) {

@@ -137,17 +137,22 @@ enum : uint32_t {
   F_GRADIENT = 1u << 13,  // gradient background
   F_ALL = (1u << 14) - 1u,
 };
-// WALK_UNIFORM: the tree is small (<= kUniformMaxLinks entries, stored in visiting order).  Every wave steps through the
-//   entries in order with a wave-uniform index, so entry, shape and object data arrive through scalar loads and live in
-//   scalar registers; a lane takes part in an entry only if its own traversal reaches it.
+// WALK_UNIFORM: the scene has few leaves (<= kFlatMaxLeaves).  Every wave steps through the list of leaves in the tree's visiting
+//   order with a wave-uniform index, so shape and object data arrive through scalar loads and live in scalar registers; every
+//   lane tests every leaf against its own shrinking t_max and no box is tested (see traverse_flat).
 // WALK_LANE: every lane follows its own hit/miss links; the first entries (top tree levels) or the whole scene sit in LDS.
 enum { WALK_UNIFORM = 0, WALK_LANE_LDS_ALL = 1, WALK_LANE_LDS_TOP = 2 };
-constexpr uint32_t kUniformMaxLinks = 96;
+constexpr uint32_t kFlatMaxLeaves = 32;
 
 template <uint32_t FEATURES, int WALK> struct Cfg {
   static constexpr uint32_t F = FEATURES;
   static constexpr int walk = WALK;
   static constexpr bool has(uint32_t f) { return (FEATURES & f) != 0u; }
+  // Small-scene presets: the double-precision kernels may replace an IEEE divide or square root by a form that differs from it
+  // by an ulp or two (reciprocal multiply, refined hardware estimates).  Their scenes have no clusters of small specular spheres
+  // that would amplify the difference, so paths still follow the reference arithmetic's to ~1e-13; the per-lane presets, whose
+  // scenes do have such clusters, keep the IEEE forms everywhere.
+  static constexpr bool relaxed() { return WALK == 0; }
 };
 constexpr uint32_t P_BOXES = F_RECT | F_BOX | F_XFORM;                                  // cornell-box
 constexpr uint32_t P_SMOKE = P_BOXES | F_MEDIUM;                                        // cornell-smoke
@@ -216,7 +221,7 @@ template <class R, class C> struct SceneView {
   const DShape<R>* shapes;
   const DObject<R>* objects;
   const uint32_t* flat;            // leaf words in visiting order (global memory, scalar loads), n_flat of them
-  uint32_t n_flat, flat_mode;
+  uint32_t n_flat;
   const FlatRect* frect;           // plain rectangles by axis (global memory, scalar loads)
   uint32_t n_frect[3];
   const FlatFace<R>* faces_lane;   // per-lane gathers (LDS)
@@ -237,7 +242,6 @@ template <class R, class C> struct SceneView {
   }
   // Scene records addressed by an index that is the same in every lane (WALK_UNIFORM): fetched through the scalar
   // data path, once per wave, whatever the lanes' execution mask is.
-  RT_DEV DLink<R> link_uniform(int i) const { return load_uniform(links + i); }
   RT_DEV DShape<R> shape(int i) const {
     if constexpr (C::walk == WALK_UNIFORM) return load_uniform(shapes + i);
     else return shapes[i];
@@ -299,7 +303,6 @@ template <class R, class C> RT_DEV SceneView<R, C> make_view(const DeviceScene<R
   v.images = sc.images;
   v.flat = reinterpret_cast<const uint32_t*>(g + sc.lay.flat_off);
   v.n_flat = sc.lay.n_flat;
-  v.flat_mode = sc.lay.flat_mode;
   v.frect = reinterpret_cast<const FlatRect*>(g + sc.lay.frect_off);
   for (int k = 0; k < 3; ++k) v.n_frect[k] = sc.lay.n_frect[k];
   return v;

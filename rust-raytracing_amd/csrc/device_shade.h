@@ -108,7 +108,7 @@ RT_DEV bool shade_hit(const SceneView<R, C>& sv, const Ray<R>& ray_in, Rec<R>& r
   scattered.time = ray_in.time;
   switch (m.tag) {
     case MAT_LAMBERTIAN: {  // src/material.rs:43-57
-      V3<R> dir = rec.n + random_unit_vector<R>(rng);
+      V3<R> dir = rec.n + random_unit_vector<R, C::relaxed()>(rng);
       if (near_zero(dir)) dir = rec.n;
       scattered.d = dir;
       attenuation = material_color<R, C>(sv, m, rec);
@@ -167,13 +167,17 @@ RT_DEV void pixel_row_col(uint32_t pixel, uint32_t W, uint32_t& y, uint32_t& i) 
   }
 }
 // (i + u) / (W - 1), src/render.rs:232-233.  Single precision multiplies by the reciprocal (wave-uniform, one rounding more).
-RT_DEV double jitter_coord(uint32_t i, double u, uint32_t wm1) { return ((double)i + u) / (double)wm1; }
-RT_DEV float jitter_coord(uint32_t i, float u, uint32_t wm1) { return ((float)i + u) * (1.0f / (float)wm1); }
+// RELAXED: double precision multiplies by the (wave-uniform) reciprocal as well.
+template <bool RELAXED> RT_DEV double jitter_coord(uint32_t i, double u, uint32_t wm1) {
+  if constexpr (RELAXED) return ((double)i + u) * (1.0 / (double)wm1);
+  else return ((double)i + u) / (double)wm1;
+}
+template <bool RELAXED> RT_DEV float jitter_coord(uint32_t i, float u, uint32_t wm1) { return ((float)i + u) * (1.0f / (float)wm1); }
 
 // Primary ray of (pixel, sample): src/render.rs:230-234 then Camera::get_ray (src/camera.rs:62-72).
 // pixel = y * W + x with y counted from the top row; the reference's j is H - 1 - y.
 // `rng` is the camera stream of (pixel, sample).
-template <class R, class S>
+template <class R, bool RELAXED, class S>
 RT_DEV Ray<R> primary_ray(const DCamera<R>& cam, uint32_t W, uint32_t H, uint32_t pixel, const S& rng) {
   uint32_t y, i;
   pixel_row_col(pixel, W, y, i);
@@ -181,8 +185,8 @@ RT_DEV Ray<R> primary_ray(const DCamera<R>& cam, uint32_t W, uint32_t H, uint32_
   const Block<R> jitter(rng, 0u);
   R u_rand = jitter.u01(0);
   R v_rand = jitter.u01(1);
-  R s = jitter_coord(i, u_rand, W - 1u);
-  R t = jitter_coord(j, v_rand, H - 1u);
+  R s = jitter_coord<RELAXED>(i, u_rand, W - 1u);
+  R t = jitter_coord<RELAXED>(j, v_rand, H - 1u);
   // a pinhole camera (lens_radius == 0) multiplies the disk sample by zero; draws are addressed, so skipping it moves nothing else
   V3<R> rd((R)0, (R)0, (R)0);
   if (cam.lens_radius != (R)0) rd = cam.lens_radius * random_in_unit_disk<R>(rng);
@@ -193,9 +197,9 @@ RT_DEV Ray<R> primary_ray(const DCamera<R>& cam, uint32_t W, uint32_t H, uint32_
   ray.o = cam.origin + offset;
   return ray;
 }
-template <class R>
+template <class R, bool RELAXED = false>
 RT_DEV Ray<R> primary_ray(const DCamera<R>& cam, uint32_t W, uint32_t H, uint32_t pixel, uint32_t sample, uint64_t seed) {
-  return primary_ray<R>(cam, W, H, pixel, Stream(seed, pixel, sample, 0u, STAGE_CAMERA));
+  return primary_ray<R, RELAXED>(cam, W, H, pixel, Stream(seed, pixel, sample, 0u, STAGE_CAMERA));
 }
 
 // color_to_rgb (src/color.rs:14-27); Rust `as u8` saturates and maps NaN to 0.

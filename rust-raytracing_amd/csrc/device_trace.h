@@ -91,6 +91,9 @@ template <class R> RT_DEV bool aabb_hit(const DLink<R>& b, const Ray<R>& ray, V3
 
 // Quadratic of src/sphere.rs:45-62 for a sphere at `center`.  Double precision: the reference's expressions as written.
 RT_DEV bool sphere_roots(V3<double> center, const Ray<double>& ray, double radius, double t_min, double t_max, double& root, bool) {
+  // never contracted into multiply-adds, whatever the translation unit's setting: `half_b^2 - a*c` cancels on the radius-1000
+  // ground spheres, and a differently rounded product there shows in t at 1e-11
+#pragma clang fp contract(off)
   V3<double> oc = ray.o - center;
   double a = length_squared(ray.d);
   double half_b = dot(oc, ray.d);

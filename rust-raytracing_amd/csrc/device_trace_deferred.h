@@ -1,5 +1,5 @@
-// Closest hit for the small-scene presets (WALK_UNIFORM): the walk only keeps the winning candidate (t, object, side)
-// and the HitRecord is built once, after the walk, from those three values.
+// Closest hit for the small-scene presets (WALK_UNIFORM) and the single-precision per-lane walk: the walk only keeps the winning
+// candidate (t, object, side) and the HitRecord is built once, after the walk, from those three values.
 //
 // The reference fills a complete HitRecord on every accepted candidate (src/sphere.rs:64-70, src/aarect.rs:99-105,
 // src/hittable.rs:229-239,146-148).  Every field of the final record is a function of the ray, the winning primitive
@@ -252,50 +252,19 @@ template <class R, class C> RT_DEV void finalize_hit(const SceneView<R, C>& sv, 
   }
 }
 
-// BVHNode::hit over a small tree stored in visiting order (an entry's hit link is the next index, its miss link a larger
-// one).  `cur` is the same in every lane of the wave, so the entry and whatever it refers to are fetched once per wave
-// by scalar loads; `want` is the entry this lane's own traversal needs next, and a lane only acts on the entries it
-// wants.  Lane by lane this performs exactly the tests of traverse_lane, in the same order, with the same shrinking t_max.
-template <class R, class C>
-RT_DEV bool traverse_uniform(const SceneView<R, C>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
-  const RayInv<R> ri(ray.d);
-  R closest = t_max;
-  int best_leaf = -1, best_side = -1;
-  const int end = (int)sv.n_links;
-  int want = start;
-  for (int cur = start; cur < end; ++cur) {
-    if (__ballot(want == cur) == 0ull) continue;
-    const DLink<R> lk = sv.link_uniform(cur);
-    const int miss = lk.miss < 0 ? end : lk.miss;
-    if (lk.hit & LEAF_FLAG) {
-      if (want == cur) {
-        R t;
-        int side;
-        if (leaf_t<R, C>(sv, lk.hit, ray, ri, t_min, closest, media, org, t, side, visit_bit(lk.hit, 0))) {
-          closest = t;
-          best_leaf = (int)(lk.hit & LEAF_INDEX_MASK);
-          best_side = side;
-        }
-        want = miss;
-      }
-    } else {
-      if (want == cur) want = aabb_hit(lk, ray, ri.inv, t_min, closest) ? cur + 1 : miss;
-    }
-  }
-  if (best_leaf < 0) return false;
-  finalize_hit<R, C>(sv, ray, closest, best_leaf, best_side, rec);
-  return true;
-}
-
 // ---- forms used by the flat walk ----
 // x in [lo, hi]; a NaN is outside.  Single precision: one median and one compare.
 RT_DEV bool in_closed(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi) == x; }
 RT_DEV bool in_closed(double x, double lo, double hi) { return (x >= lo) & (x <= hi); }
 
 // Reciprocal of a direction component for the flat walk.  Single precision: the hardware estimate (1 ulp).  Double precision: the
-// IEEE quotient 1/d, which is what Aabb::hit multiplies by (src/aabb.rs:33).
+// quotient 1/d, which is what Aabb::hit multiplies by (src/aabb.rs:33), from the refined hardware estimate.
 RT_DEV float flat_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#ifdef RT_EXP_IEEE_RCP
 RT_DEV double flat_rcp(double x) { return 1.0 / x; }
+#else
+RT_DEV double flat_rcp(double x) { return rcp_refined(x); }
+#endif
 RT_DEV float next_up(float x) { return nextafterf(x, Lim<float>::inf()); }
 RT_DEV double next_up(double x) { return nextafter(x, Lim<double>::inf()); }
 
@@ -666,8 +635,7 @@ RT_DEV bool traverse_lane_deferred(const SceneView<float, C>& sv, int start, con
 template <class R, class C>
 RT_DEV bool closest_hit(const SceneView<R, C>& sv, int root, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
   if constexpr (C::walk == WALK_UNIFORM) {
-    if (sv.flat_mode != 0u) return traverse_flat<R, C>(sv, root, ray, t_min, t_max, rec, media, org);
-    return traverse_uniform<R, C>(sv, root, ray, t_min, t_max, rec, media, org);
+    return traverse_flat<R, C>(sv, root, ray, t_min, t_max, rec, media, org);
   } else {
     if constexpr (sizeof(R) == sizeof(float)) return traverse_lane_deferred<C>(sv, root, ray, t_min, t_max, rec, media, org);
     else return traverse_lane<R, C, 0>(sv, root, ray, t_min, t_max, rec, media, org);

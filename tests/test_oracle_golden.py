@@ -137,14 +137,23 @@ def test_philox_published_vectors(oracle):
 
 def test_stream_layout(oracle):
     # draw slot s = H[s & 3] << 32 | L[s & 3]; H = Philox block s >> 2 with counter (block, bounce | stage << 16, seed_lo, seed_hi),
-    # L = the same with bit 20 of the second counter word set; key (pixel, sample)
+    # key (pixel, sample); L[j] = low_mix(H[j], H[(j + 1) & 3]) * 0x846CA68B, a multiplicative hash of the Philox words
+    def low_mix(a, b):
+        m = ((a ^ (((b << 16) | (b >> 16)) & 0xffffffff)) * 0x7FEB352D) & 0xffffffff
+        return m ^ (m >> 15)
+
     seed, pixel, sample, bounce, stage = 0x1122334455667788, 12345, 67, 9, 2
     words = oracle.stream_words(seed, pixel, sample, bounce, stage, 12)
     for blk in range(3):
-        h = oracle.philox([blk, bounce | (stage << 16), seed & 0xffffffff, seed >> 32], [pixel, sample])
-        l = oracle.philox([blk, bounce | (stage << 16) | (1 << 20), seed & 0xffffffff, seed >> 32], [pixel, sample])
+        h = [int(x) for x in oracle.philox([blk, bounce | (stage << 16), seed & 0xffffffff, seed >> 32], [pixel, sample])]
         for j in range(4):
-            assert int(words[4 * blk + j]) == (int(h[j]) << 32) | int(l[j])
+            low = (low_mix(h[j], h[(j + 1) & 3]) * 0x846CA68B) & 0xffffffff
+            assert int(words[4 * blk + j]) == (h[j] << 32) | low
+    # the low halves are spread evenly: mean of 4096 of them as fractions of 2^32 within 4 sigma of 1/2
+    w = oracle.stream_words(7, 1, 2, 3, 0, 4096)
+    low = (w & np.uint64(0xffffffff)).astype(np.float64) / 2.0 ** 32
+    assert abs(low.mean() - 0.5) < 4 * (1 / 12 ** 0.5) / 64
+    assert abs(np.corrcoef(low, (w >> np.uint64(32)).astype(np.float64))[0, 1]) < 0.08
 
 
 def test_pcg32_reference_stream(oracle):
