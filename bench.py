@@ -214,13 +214,13 @@ def main():
                 t = json.load(f).get("%s_%s_%s" % (args.scene, name, "persistent" if persistent else args.pipeline))
             if t is not None:  # bytes per frame at the profiled sample count -> per launch of this run
                 traffic = t["bytes_per_frame"] * (args.spp / t["spp"]) * (s1 - s0) / args.spp / (leg["launches"] / max(1, args.steps))
-                with open(os.path.join(REPO, "profiles", "%s_pmc.json" % t["from"])) as f:
+                with open(os.path.join(REPO, "profiles", "%s.json" % t["from"])) as f:
                     k = json.load(f)["kernels"]
                 k = k.get("k_paths_persistent") or k.get("k_paths_stepwise") or {}
                 if persistent and "valu_insts_per_simd_cycle" in k:
                     issue = {"valu_insts_per_simd_cycle": k["valu_insts_per_simd_cycle"], "salu_insts_per_cu_cycle": k.get("salu_insts_per_cu_cycle"),
                              "lanes_active_of_64": k.get("lanes_active_per_valu_cycle"),
-                             "source": "profiles/%s_pmc.json" % t["from"]}
+                             "source": "profiles/%s.json" % t["from"]}
         except (OSError, KeyError, ValueError):
             pass
         # bytes the algorithm has to move per ray: the queue pipelines read and write one queue entry per ray; the persistent
