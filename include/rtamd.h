@@ -212,6 +212,17 @@ int rt_read_accum(rt_context* ctx, const void* accum_dev, uint32_t width, uint32
  * `accum_out` (optional) receives the width*height*3 linear sums as doubles. */
 int rt_render(rt_context* ctx, const rt_render_params* params, uint8_t* rgb8_out, double* accum_out, rt_stats* stats);
 
+/* rt_render() for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  No counterpart in the reference (its render() allocates freely); it exists for those callers only.
+ * The call allocates and frees nothing, on the device or through any allocating routine: the counters and the RGB8 staging
+ * image live in a static device array inside the library (about 24 MiB on every GPU the library runs on, held until the process
+ * ends), everything else is the caller's.
+ *   accum_dev  DEVICE buffer of width*height*4 floats (F32) or doubles (F64), required; zeroed by the call, receives the sums
+ *   rgb8_out   host buffer of width*height*3 bytes, required (page-locked memory makes the copy one DMA)
+ * Limits: width*height <= 3840*2160 (RT_E_INVALID beyond), pipeline AUTO or PERSISTENT (RT_E_UNSUPPORTED otherwise).
+ * Every call on a GPU uses that GPU's one scratch array: calls that overlap on the same GPU (two contexts, two threads) race. */
+int rt_render_noalloc(rt_context* ctx, const rt_render_params* params, void* accum_dev, uint8_t* rgb8_out, rt_stats* stats);
+
 /* ---- first-hit batches: world.hit(ray, tmin, tmax, rec) through the BVH (src/bvh.rs:108-119) ---- */
 typedef struct rt_ray {
   double origin[3], direction[3], time, tmin, tmax;

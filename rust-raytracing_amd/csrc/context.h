@@ -75,6 +75,8 @@ struct rt_context {
   void* accum = nullptr;
   size_t accum_bytes = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned long long* h_rays = nullptr;  // one page-locked host word: where the allocation-free entry point receives its ray count
+  void* scratch = nullptr;               // this device's address of the library's static scratch array (see rtamd_api.hip)
 };
 
 namespace rti {
@@ -104,7 +106,9 @@ template <class R> void layout_sections(rtd::BlobLayout& lay);
 template <class R>
 int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink>& links, int root_link, const std::vector<int>& sub_root_of_object,
                 int preset, SceneImage<R>& im);
-template <class R> int render_accum_impl(rt_context* c, const rt_render_params& p, void* accum_dev, rt_stats* stats);
+template <class R>
+int render_accum_impl(rt_context* c, const rt_render_params& p, void* accum_dev, rt_stats* stats, unsigned long long* counters_override = nullptr,
+                      unsigned long long* host_rays = nullptr);
 template <class R> int trace_batch_impl(rt_context* c, const rt_ray* rays, size_t n, rt_hit* hits, uint64_t seed, bool as_rendered);
 template <class R>
 int pairs_kernel_impl(rt_context* c, int which, uint32_t W, uint32_t H, uint32_t max_depth, const uint32_t* pixel, const uint32_t* sample, size_t n,

@@ -226,7 +226,10 @@ inline int ensure_ws(rt_context* c, size_t bytes) {
   return RT_OK;
 }
 
-template <class R> int render_accum_impl(rt_context* c, const rt_render_params& p, void* accum_dev, rt_stats* stats) {
+// `counters` / `host_rays`: the allocation-free entry point hands in its static scratch words and a page-locked host word; the
+// ordinary entry points pass NULL and use the context's counter block and a stack variable.
+template <class R> int render_accum_impl(rt_context* c, const rt_render_params& p, void* accum_dev, rt_stats* stats, unsigned long long* counters_override,
+                                         unsigned long long* host_rays) {
   using R4 = typename Vec4<R>::type;
   SceneImage<R>& im = image_of<R>(c);
   const uint64_t n_pixels = (uint64_t)p.width * p.height;
@@ -241,15 +244,17 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
   }
   if (p.pipeline == RT_PIPELINE_PERSISTENT || p.pipeline == RT_PIPELINE_AUTO) {
     // one launch for the whole sample range; no ray queues
+    unsigned long long* const cnt = counters_override ? counters_override : c->d_ray_count;
     FrameParams fp{};
     fp.width = p.width; fp.height = p.height; fp.n_pixels = (uint32_t)n_pixels;
     fp.sample_base = p.sample_begin; fp.n_paths = 0; fp.max_depth = p.max_depth; fp.seed = p.seed;
     fp.n_seg = kSegments; fp.seg_cap = 0;
     const unsigned long long total_paths = (unsigned long long)n_pixels * n_samples;
 #ifdef RT_STAMPS
+    if (counters_override) return fail(RT_E_UNSUPPORTED, "the diagnostic build has no allocation-free entry point");
     HIP_TRY(hipMemsetAsync(c->d_ray_count, 0, sizeof(unsigned long long) * kRayCountWords, c->stream));
 #else
-    HIP_TRY(hipMemsetAsync(c->d_ray_count, 0, sizeof(unsigned long long) * 16, c->stream));  // word 0 rays, word 8 path cursor
+    HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * 16, c->stream));  // word 0 rays, word 8 path cursor
 #endif
     const uint32_t bpc = resident_blocks(im.table.resident_blocks_per_cu(3, im.lds_bytes));
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->n_cus * bpc, (total_paths + kBlock - 1) / kBlock));
@@ -262,12 +267,14 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
     }
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     if (p.max_depth > 0 && total_paths > 0)
-      im.table.paths_persistent(grid, im.lds_bytes, c->stream, im.dev, fp, total_paths, c->d_ray_count + 8, c->d_ray_count, accum);
+      im.table.paths_persistent(grid, im.lds_bytes, c->stream, im.dev, fp, total_paths, cnt + 8, cnt, accum);
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     HIP_TRY(hipGetLastError());
-    unsigned long long rays = 0;
-    HIP_TRY(hipMemcpyAsync(&rays, c->d_ray_count, sizeof(rays), hipMemcpyDeviceToHost, c->stream));
+    unsigned long long rays_stack = 0;
+    unsigned long long* const rays_dst = host_rays ? host_rays : &rays_stack;
+    HIP_TRY(hipMemcpyAsync(rays_dst, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    const unsigned long long rays = *rays_dst;
 #ifdef RT_STAMPS
     {
       std::vector<unsigned long long> all(kRayCountWords);
@@ -296,6 +303,7 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
     }
     return RT_OK;
   }
+  if (counters_override) return fail(RT_E_UNSUPPORTED, "the allocation-free entry point renders with the persistent pipeline only");
   uint32_t spp_pass = p.samples_per_pass ? p.samples_per_pass : (uint32_t)std::max<uint64_t>(1, kTargetPathsPerPass / n_pixels);
   spp_pass = std::max(1u, std::min(spp_pass, std::max(1u, n_samples)));
   if (n_pixels * spp_pass > 0x7FFFFFFFull) return fail(RT_E_INVALID, "width*height*samples_per_pass exceeds 2^31-1");
@@ -485,7 +493,7 @@ template <class R> int resolve_impl(rt_context* c, const void* accum_dev, size_t
 #define RTI_INSTANTIATE(R)                                                                                                                   \
   template void layout_sections<R>(BlobLayout&);                                                                                        \
   template int build_image<R>(rt_context*, const rt_scene_desc&, const std::vector<TmpLink>&, int, const std::vector<int>&, int, SceneImage<R>&); \
-  template int render_accum_impl<R>(rt_context*, const rt_render_params&, void*, rt_stats*);                                                \
+  template int render_accum_impl<R>(rt_context*, const rt_render_params&, void*, rt_stats*, unsigned long long*, unsigned long long*);                                              \
   template int trace_batch_impl<R>(rt_context*, const rt_ray*, size_t, rt_hit*, uint64_t, bool);                                                  \
   template int pairs_kernel_impl<R>(rt_context*, int, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint32_t*, size_t, uint64_t, void*, \
                                     size_t);                                                                                               \

@@ -5,10 +5,40 @@
 #include "accel_build.h"
 #include "context.h"
 
+#include <mutex>
+
 namespace rti {
 thread_local std::string g_err;
 }
 using namespace rti;
+
+// ---- static scratch of rt_render_noalloc ----
+// Everything that entry point needs on the device beyond the caller's buffers: 16 counter words (ray count, path cursor) and the
+// RGB8 image between the colour conversion and the copy to the host.  A file-scope device array: every GPU the library runs on
+// holds its own copy, at its own address, until the process ends.  In host code the array's NAME is only a handle for
+// hipGetSymbolAddress; the address that call returns (kept per device below) is what kernels, memsets and copies are given.
+#define RT_NOALLOC_MAX_PIXELS (3840u * 2160u)
+#define RT_NOALLOC_COUNTER_BYTES 256u
+static __device__ __align__(256) unsigned char g_noalloc_scratch[RT_NOALLOC_COUNTER_BYTES + (size_t)RT_NOALLOC_MAX_PIXELS * 3u];
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_of_device[kMaxDevices] = {};  // device address of g_noalloc_scratch on each device, once looked up
+
+// With `device` current: the address of this device's copy of the scratch array (looked up once per device).
+int scratch_for_device(int device, void** out) {
+  if (device < 0 || device >= kMaxDevices) return fail(RT_E_NO_DEVICE, "device index beyond the scratch table");
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_of_device[device]) {
+    void* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_noalloc_scratch));
+    if (e != hipSuccess || !ptr) return fail(RT_E_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+    g_scratch_of_device[device] = ptr;
+  }
+  *out = g_scratch_of_device[device];
+  return RT_OK;
+}
+}  // namespace
 
 namespace {
 
@@ -177,6 +207,9 @@ int rt_create(rt_context** out, int device) {
     if (hipEventCreate(&ev) != hipSuccess) return cleanup(RT_E_HIP, "hipEventCreate failed");
   if (hipMalloc((void**)&c->d_counters, sizeof(uint32_t) * kCounterWords) != hipSuccess) return cleanup(RT_E_HIP, "hipMalloc counters failed");
   if (hipMalloc((void**)&c->d_ray_count, sizeof(unsigned long long) * rti::kRayCountWords) != hipSuccess) return cleanup(RT_E_HIP, "hipMalloc ray counter failed");
+  if (hipHostMalloc((void**)&c->h_rays, 64, hipHostMallocDefault) != hipSuccess) return cleanup(RT_E_HIP, "hipHostMalloc failed");
+  // set-up of the allocation-free entry point: this device's address of the static scratch array, looked up with the device current
+  if (int rc = scratch_for_device(device, &c->scratch)) { std::string m = g_err; return cleanup(rc, m); }
   *out = c;
   return RT_OK;
 }
@@ -190,6 +223,7 @@ void rt_destroy(rt_context* c) {
   if (c->accum) (void)hipFree(c->accum);
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->d_ray_count) (void)hipFree(c->d_ray_count);
+  if (c->h_rays) (void)hipHostFree(c->h_rays);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -442,6 +476,37 @@ int rt_render(rt_context* c, const rt_render_params* p, uint8_t* rgb8_out, doubl
   if (rc == RT_OK && accum_out) rc = rt_read_accum(c, nullptr, p->width, p->height, p->precision, accum_out);
   if (stats) stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return rc;
+}
+
+int rt_render_noalloc(rt_context* c, const rt_render_params* p, void* accum_dev, uint8_t* rgb8_out, rt_stats* stats) {
+  int rc = check_render_params(c, p);
+  if (rc) return rc;
+  if (!accum_dev || !rgb8_out) return fail(RT_E_INVALID, "rt_render_noalloc: accum_dev and rgb8_out are required (this entry point owns no buffers)");
+  if (p->pipeline != RT_PIPELINE_AUTO && p->pipeline != RT_PIPELINE_PERSISTENT)
+    return fail(RT_E_UNSUPPORTED, "rt_render_noalloc: the queue pipelines need a workspace; only RT_PIPELINE_AUTO / RT_PIPELINE_PERSISTENT");
+  const size_t n = (size_t)p->width * p->height;
+  if (n > (size_t)RT_NOALLOC_MAX_PIXELS)
+    return fail(RT_E_INVALID, "rt_render_noalloc: frame larger than the static scratch holds (at most 3840*2160 = 8294400 pixels)");
+  if (p->sample_end == p->sample_begin) return fail(RT_E_INVALID, "cannot resolve an image of zero samples");
+  if (!c->scratch) return fail(RT_E_HIP, "rt_render_noalloc: no scratch address for this device");
+  auto t0 = std::chrono::steady_clock::now();
+  HIP_TRY(hipSetDevice(c->device));
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  const bool f64 = p->precision == RT_PRECISION_F64;
+  unsigned char* const scratch = static_cast<unsigned char*>(c->scratch);  // the device address, never the array's name
+  unsigned long long* const counters = reinterpret_cast<unsigned long long*>(scratch);
+  uint8_t* const d_rgb = scratch + RT_NOALLOC_COUNTER_BYTES;
+  // the whole frame, as rt_render: sums start at zero; the counters are cleared inside (the array keeps the last call's contents)
+  HIP_TRY(hipMemsetAsync(accum_dev, 0, n * 4 * (f64 ? sizeof(double) : sizeof(float)), c->stream));
+  rc = f64 ? render_accum_impl<double>(c, *p, accum_dev, stats, counters, c->h_rays) : render_accum_impl<float>(c, *p, accum_dev, stats, counters, c->h_rays);
+  if (rc) return rc;
+  const uint32_t spp = p->sample_end - p->sample_begin;
+  rc = f64 ? resolve_impl<double>(c, accum_dev, n, spp, d_rgb) : resolve_impl<float>(c, accum_dev, n, spp, d_rgb);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(rgb8_out, d_rgb, n * 3, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (stats) stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return RT_OK;
 }
 
 int rt_trace_batch(rt_context* c, const rt_ray* rays, size_t n, rt_hit* hits, int precision, uint64_t seed) {

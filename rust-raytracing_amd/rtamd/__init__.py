@@ -27,7 +27,7 @@ SCENES = {
 }
 
 # every symbol include/rtamd.h and include/rtamd_host.h declare
-ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_upload_scene", "rt_render_accum", "rt_resolve", "rt_read_accum", "rt_render",
+ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_upload_scene", "rt_render_accum", "rt_resolve", "rt_read_accum", "rt_render", "rt_render_noalloc",
                "rt_trace_batch", "rt_camera_rays", "rt_sample_radiance", "rt_sample_path", "rt_last_error", "rt_version"]
 HOST_ABI_SYMBOLS = ["rth_scene_create", "rth_scene_destroy", "rth_scene_desc", "rth_scene_config", "rth_scene_from_name",
                     "rth_scene_name", "rth_save_image", "rth_load_ppm", "rth_free", "rth_render_and_save", "rth_last_error"]
@@ -109,6 +109,7 @@ def load_libraries():
     L.rt_resolve.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp]
     L.rt_read_accum.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_int, vp]
     L.rt_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
+    L.rt_render_noalloc.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
     L.rt_trace_batch.argtypes = [vp, vp, C.c_size_t, vp, C.c_int, C.c_uint64]
     L.rt_camera_rays.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, C.c_size_t, C.c_uint64, C.c_int, vp]
     L.rt_sample_radiance.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, C.c_size_t, C.c_uint64, C.c_int, vp]
@@ -261,6 +262,14 @@ class Context:
         p = self._params(width, height, s_begin, s_end, depth, precision, pipeline, samples_per_pass, seed)
         st = Stats()
         _check(self.L.rt_render_accum(self.h, C.byref(p), C.c_void_p(accum_dev_ptr) if accum_dev_ptr else None, C.byref(st)))
+        return st.as_dict()
+
+    def render_noalloc(self, accum_dev_ptr, rgb_out, s_begin, s_end, precision=F32, pipeline=PIPELINE_AUTO, seed=0, depth=None, width=0, height=0):
+        """rt_render_noalloc: whole frame into the caller's DEVICE sums (address as int) and host RGB8 array; nothing is allocated."""
+        p = self._params(width, height, s_begin, s_end, depth, precision, pipeline, 0, seed)
+        assert rgb_out.dtype == np.uint8 and rgb_out.size == p.width * p.height * 3 and rgb_out.flags["C_CONTIGUOUS"]
+        st = Stats()
+        _check(self.L.rt_render_noalloc(self.h, C.byref(p), C.c_void_p(accum_dev_ptr), _p(rgb_out), C.byref(st)))
         return st.as_dict()
 
     def resolve(self, accum_dev_ptr, width, height, spp, precision=F32, out=None):
