@@ -402,11 +402,19 @@ struct orc_hit {
   double t, p[3], n[3], u, v;
 };
 
-template <class R> static void first_hit_impl(const Scene<R>& sc, uint64_t seed, size_t n, const orc_ray* rays, orc_hit* hits) {
+// `skip` (optional): per ray, the winner of an earlier query; that surface - and every exact copy of its object, by
+// `class_of_obj` - is left out, so the query returns the runner-up.
+template <class R>
+static void first_hit_impl(const Scene<R>& sc, uint64_t seed, size_t n, const orc_ray* rays, orc_hit* hits, const orc_hit* skip = nullptr,
+                           const int32_t* class_of_obj = nullptr) {
   for (size_t r = 0; r < n; ++r) {
     Ray<R> ray{V3<R>((R)rays[r].o[0], (R)rays[r].o[1], (R)rays[r].o[2]), V3<R>((R)rays[r].d[0], (R)rays[r].d[1], (R)rays[r].d[2]), (R)rays[r].time};
     Stream media(seed, rays[r].pixel, rays[r].sample, rays[r].bounce, STAGE_MEDIA);
     HitCtx ctx{&media};
+    if (skip && class_of_obj && skip[r].hit && skip[r].obj >= 0) {
+      ctx.class_of_obj = class_of_obj;
+      ctx.skip_class = class_of_obj[skip[r].obj]; ctx.skip_sub = skip[r].sub; ctx.skip_side = skip[r].side;
+    }
     HitRecord<R> rec;
     bool h = sc.bvh->hit(ray, (R)rays[r].tmin, (R)rays[r].tmax, rec, ctx);
     orc_hit& o = hits[r];
@@ -472,6 +480,15 @@ void orc_camera_rays(const orc_scene* s, uint64_t seed, size_t n, const uint32_t
 int orc_first_hit(const orc_scene* s, uint64_t seed, size_t n, const orc_ray* rays, orc_hit* hits, int precision) {
   if (precision == 1) first_hit_impl<double>(*s->d, seed, n, rays, hits);
   else { if (!s->f) return 1; first_hit_impl<float>(*s->f, seed, n, rays, hits); }
+  return 0;
+}
+
+// The same query with the surface each ray hit first (`winners`, from orc_first_hit) left out, together with every object of the
+// same class (class_of_obj[n_objects]: exact copies of an object share a class): the runner-up candidate, for the near-tie sets of
+// the parity tests.  f64 only.
+int orc_first_hit_runner_up(const orc_scene* s, uint64_t seed, size_t n, const orc_ray* rays, const orc_hit* winners, const int32_t* class_of_obj,
+                            orc_hit* hits) {
+  first_hit_impl<double>(*s->d, seed, n, rays, hits, winners, class_of_obj);
   return 0;
 }
 

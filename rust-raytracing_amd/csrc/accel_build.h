@@ -134,6 +134,28 @@ class FastTreeBuilder {
     return v;
   }
 
+  // A sphere of negative radius (the hollow-glass trick, src/scenes.rs:235-239) reports an inverted box (src/sphere.rs:75-81),
+  // which barely widens its parent's box in the reference's tree: there the sphere is only ever tested by rays that pass the box
+  // of the node holding it, and rays that miss that box see through the shell.  The tree built here reproduces that: such a
+  // sphere stands behind a box entry of its own carrying the box of its node in the reference's tree.
+  bool has_guard(int o) const {
+    const rt_object& ob = s_.objects[o];
+    if (ob.flags & (RT_OBJ_SUB_BVH | RT_OBJ_MEDIUM)) return false;
+    const rt_shape& sh = s_.shapes[ob.geom];
+    return (sh.tag == RT_SHAPE_SPHERE && sh.p[3] < 0.0) || (sh.tag == RT_SHAPE_MOVING_SPHERE && sh.p[6] < 0.0);
+  }
+  Box3d guard_box(int o) const {
+    Box3d b;
+    b.reset();
+    for (int n = 0; n < s_.n_nodes; ++n)
+      if (s_.nodes[n].left == ~o || s_.nodes[n].right == ~o) {
+        Box3d nb;
+        for (int k = 0; k < 3; ++k) { nb.mn[k] = s_.nodes[n].bmin[k]; nb.mx[k] = s_.nodes[n].bmax[k]; }
+        b.grow(nb);
+      }
+    return b;
+  }
+
   static Box3d sphere_box(const double c[3], double r) {
     r = std::fabs(r);
     Box3d b;
@@ -267,7 +289,7 @@ class FastTreeBuilder {
 
   uint32_t leaf_word(int obj) const {
     const uint32_t f = s_.objects[obj].flags;
-    return LEAF_FLAG | (f == 0u ? LEAF_SIMPLE : 0u) | ((f & RT_OBJ_SUB_BVH) ? LEAF_NESTED : 0u) | (uint32_t)obj;
+    return LEAF_FLAG | ((f & 15u) == 0u ? LEAF_SIMPLE : 0u) | ((f & RT_OBJ_SUB_BVH) ? LEAF_NESTED : 0u) | (uint32_t)obj;
   }
   // Emits the subtree of `n` in visiting order; returns the index of its first link.
   int emit(const std::vector<Node>& nodes, int n, int next, int depth, int tree, std::vector<TmpLink>& out) const {
@@ -276,9 +298,17 @@ class FastTreeBuilder {
     l.depth = depth; l.tree = tree; l.miss = next;
     const int me = (int)out.size();
     if (nd.obj >= 0) {
+      if (has_guard(nd.obj)) {  // see guard_box(): a box entry of its own in front of the leaf
+        const Box3d g = guard_box(nd.obj);
+        TmpLink b = l;
+        for (int k = 0; k < 3; ++k) { b.bmin[k] = g.mn[k]; b.bmax[k] = g.mx[k]; }
+        b.hit = (uint32_t)(me + 1);
+        out.push_back(b);
+        l.depth = depth + 1;
+      }
       l.hit = leaf_word(nd.obj);
       if (!twice_.empty() && twice_[(size_t)nd.obj]) {  // both visits, the second right behind the first
-        l.miss = me + 1;
+        l.miss = (int)out.size() + 1;
         out.push_back(l);
         l.hit |= LEAF_SECOND;
         l.miss = next;
@@ -313,7 +343,14 @@ class FastTreeBuilder {
     for (int o : objs_in_order) {
       const rt_object& ob = s_.objects[o];
       if (ob.flags & (RT_OBJ_MEDIUM | RT_OBJ_SUB_BVH)) continue;
-      if (last[signature(o)] == o) keep.push_back(o);
+      if (last[signature(o)] != o) continue;
+      if (has_guard(o)) {
+        // alone in a one-object node, the inverted box IS the node's box, and the reference's box test (src/aabb.rs:30-46) fails
+        // for every ray: the sphere is never tested there, so it is not part of this tree either
+        const Box3d g = guard_box(o);
+        if (g.mn[0] > g.mx[0] || g.mn[1] > g.mx[1] || g.mn[2] > g.mx[2]) continue;
+      }
+      keep.push_back(o);
     }
     std::vector<Box3d> boxes((size_t)s_.n_objects);
     for (int o : keep) boxes[(size_t)o] = object_box(o);

@@ -39,7 +39,11 @@ template <class R> struct alignas(16) DLink {  // 32 B (float) / 64 B (double)
 enum { SH_SPHERE = 0, SH_MOVING = 1, SH_RECT_XY = 2, SH_RECT_XZ = 3, SH_RECT_YZ = 4, SH_BOX = 5 };
 enum { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_LIGHT = 3, MAT_ISOTROPIC = 4, MAT_CLASSES = 5 };
 enum { TEX_SOLID = 0, TEX_CHECKER = 1, TEX_NOISE = 2, TEX_IMAGE = 3 };
-enum : uint32_t { OBJ_TRANSLATE = 1u, OBJ_ROTATE_Y = 2u, OBJ_MEDIUM = 4u, OBJ_SUB_BVH = 8u };
+enum : uint32_t { OBJ_TRANSLATE = 1u, OBJ_ROTATE_Y = 2u, OBJ_MEDIUM = 4u, OBJ_SUB_BVH = 8u,
+                  // library-internal (never in rt_object as the caller passes it): a sphere that stood under Translate(RotateY(..)) and
+                  // was re-centred at upload.  It is tested like a bare sphere; only its front_face flag goes through the chain of
+                  // set_face_normal calls the wrappers would have made (sin_theta / cos_theta are the holder's).
+                  OBJ_FRONT_CHAIN = 16u };
 
 template <class R> struct alignas(16) DShape {  // one per object, indexed by object
   int32_t tag, material, obj_id, sub_id;

@@ -196,6 +196,16 @@ template <class R, class C> RT_DEV void finalize_hit(const SceneView<R, C>& sv, 
       V3<R> outward = vdiv(p - center, radius);
       rec.p = p;
       rec.set_face_normal(local.d, outward);
+      if constexpr (C::has(F_XFORM)) {
+        if (ob.flags & OBJ_FRONT_CHAIN) {
+          // A sphere re-centred from under Translate(RotateY(..)): the normal ends up against the ray either way, but front_face
+          // is what RotateY's call left - the rotated normal against the direction in the UNrotated frame (src/hittable.rs:236-239);
+          // Translate's call (src/hittable.rs:146-148) then reports whether that one already faced the ray.
+          const R dlx = ob.cos_theta * ray.d.x - ob.sin_theta * ray.d.z, dlz = ob.sin_theta * ray.d.x + ob.cos_theta * ray.d.z;
+          const R mixed = dlx * rec.n.x + ray.d.y * rec.n.y + dlz * rec.n.z;
+          rec.front = mixed < (R)0;
+        }
+      }
       if constexpr (C::has(F_UV)) {
         if (s.tag == SH_SPHERE) { rec.u = outward.x; rec.v = outward.y; rec.uw = outward.z; rec.uv_lazy = 1; }
       }

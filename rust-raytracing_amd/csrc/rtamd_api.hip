@@ -65,7 +65,7 @@ struct LinkBuilder {
   std::string err;
   explicit LinkBuilder(const rt_scene_desc& sc) : s(sc), node_seen((size_t)std::max(0, sc.n_nodes), 0) {}
 
-  bool simple(int obj) const { return s.objects[obj].flags == 0u; }
+  bool simple(int obj) const { return (s.objects[obj].flags & 15u) == 0u; }
 
   int leaf(int obj, int next, int depth, int tree) {
     TmpLink l{};
@@ -280,9 +280,15 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   projected.n_links = (uint32_t)lb.links.size(); projected.n_objects = (uint32_t)s->n_objects; projected.n_materials = (uint32_t)s->n_materials;
   projected.n_textures = (uint32_t)std::max(1, s->n_textures); projected.n_perlins = (uint32_t)s->n_perlins; projected.flat_mode = 1u;
   layout_sections<double>(projected);
+  bool inverted_box = false;  // a sphere of negative radius: what it is reachable through is decided by the tree (see accel_build.h)
+  for (int i = 0; i < s->n_objects; ++i) {
+    if (s->objects[i].flags & RT_OBJ_SUB_BVH) continue;
+    const rt_shape& sh = s->shapes[s->objects[i].geom];
+    inverted_box = inverted_box || (sh.tag == RT_SHAPE_SPHERE && sh.p[3] < 0.0) || (sh.tag == RT_SHAPE_MOVING_SPHERE && sh.p[6] < 0.0);
+  }
   size_t n_leaf_links = 0;
   for (const TmpLink& l : lb.links) n_leaf_links += (l.hit & LEAF_FLAG) ? 1u : 0u;
-  const bool small = n_leaf_links <= kFlatMaxLeaves && !has_nested && !(force && force[0] == '1') && !std::getenv("RTAMD_NO_FLAT") &&
+  const bool small = n_leaf_links <= kFlatMaxLeaves && !has_nested && !inverted_box && !(force && force[0] == '1') && !std::getenv("RTAMD_NO_FLAT") &&
                      projected.total_bytes <= kLdsAllMax;
   int preset = PRESET_ALL_LDS;  // build_image demotes to PRESET_ALL_TOP when the image does not fit in LDS
   if (small && (feat & ~P_BOXES) == 0) preset = PRESET_BOXES;
@@ -371,6 +377,10 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
           moved.p[1] = sh.p[1] + (tr ? holder.offset[1] : 0.0);
           moved.p[2] = -sn * sh.p[0] + cs * sh.p[2] + (tr ? holder.offset[2] : 0.0);
           o.geom = (int32_t)shapes32.size() - 1;
+          if (rot) {  // front_face still goes through the wrappers' set_face_normal calls (read by nothing but Dielectric, reported by rt_trace_batch)
+            o.flags = OBJ_FRONT_CHAIN;
+            o.sin_theta = holder.sin_theta; o.cos_theta = holder.cos_theta;
+          }
           continue;
         }
         o.flags = holder.flags & (RT_OBJ_TRANSLATE | RT_OBJ_ROTATE_Y);

@@ -70,6 +70,8 @@ def lib():
         L.orc_camera_rays.argtypes = [C.c_void_p, C.c_uint64, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_first_hit.argtypes = [C.c_void_p, C.c_uint64, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_first_hit.restype = C.c_int
+        L.orc_first_hit_runner_up.argtypes = [C.c_void_p, C.c_uint64, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_first_hit_runner_up.restype = C.c_int
         L.orc_render.restype = C.c_double
         L.orc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                  C.c_int]
@@ -149,6 +151,16 @@ class OracleScene:
         rc = lib().orc_first_hit(self.h, seed, rays.size, _p(rays), _p(hits), precision)
         if rc:
             raise RuntimeError("orc_first_hit failed (f32 scene not built?)")
+        return hits
+
+    def runner_up(self, rays, winners, class_of_obj, seed=0):
+        """The closest hit with each ray's winner (and the exact copies of its object) left out."""
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        winners = np.ascontiguousarray(winners, dtype=HIT_DTYPE)
+        cls = np.ascontiguousarray(class_of_obj, dtype=np.int32)
+        assert cls.size >= self.n_objects
+        hits = np.zeros(rays.size, dtype=HIT_DTYPE)
+        lib().orc_first_hit_runner_up(self.h, seed, rays.size, _p(rays), _p(winners), _p(cls), _p(hits))
         return hits
 
     def render(self, s_begin, s_end, seed=0, threads=None, rows=None, precision=1, accum=None):
