@@ -230,7 +230,7 @@ class Context:
         self.close()
 
     def upload(self, scene):
-        ptr = scene.desc_ptr if isinstance(scene, Scene) else scene
+        ptr = scene.desc_ptr if hasattr(scene, "desc_ptr") else scene  # a Scene, anything else that owns an rt_scene_desc, or its address
         _check(self.L.rt_upload_scene(self.h, ptr))
         self.scene = scene
 

@@ -155,7 +155,7 @@ T_REL_BOUND = {name: 1e-5 for name in ALL_SCENES}
 T_REL_BOUND["final-scene"] = 4e-5
 
 
-def check_f32(name, hs, os_, gpu_hits, rays, oh, seed, rng, camera):
+def check_f32(name, hs, os_, gpu_hits, rays, oh, seed, rng, camera, max_excluded=0.005):
     decided, sizes = decided_rays(hs, os_, rays, oh, seed, rng, SCENE_EXTENT[name])
     excluded = 1.0 - decided.mean()
     same = np.ones(rays.size, dtype=bool)
@@ -169,7 +169,7 @@ def check_f32(name, hs, os_, gpu_hits, rays, oh, seed, rng, camera):
           "decided rays: %d id mismatches, max rel t err %.3g, max distance err %.3g"
           % (name, "camera" if camera else "random", 100 * excluded, 100 * sizes["near_tie"], 100 * sizes["grazing"], 100 * sizes["unstable"],
              100 * (1 - same.mean()), bad.size, t_rel.max(), derr.max()))
-    assert excluded < 0.005, (name, excluded, sizes)
+    assert excluded < max_excluded, (name, excluded, sizes)
     assert bad.size == 0, "%s: %d decided rays differ in ids, first: gpu %s oracle %s ray %s" % (name, bad.size, gpu_hits[bad[:1]], oh[bad[:1]], rays[bad[:1]])
     return t_rel, derr
 
@@ -259,3 +259,86 @@ def test_f32_tree_variants_agree(gpu, rtamd, oracle, earth_rgb, name, switch, mo
     t_err = np.abs(a["t"][both] - b["t"][both]) / np.maximum(np.abs(a["t"][both]), 1e-30)
     assert np.quantile(t_err, 0.999) < 1e-4, (name, switch, np.quantile(t_err, 0.999))
 
+
+
+def test_medium_in_a_one_object_node(gpu, rtamd, oracle, earth_rgb):
+    """With axis seed 13 the reference's tree of final-scene puts the fog-filled glass ball (object 6 of the world list, a
+    ConstantMedium) alone into a one-object node, which holds it twice (src/bvh.rs:38) and calls it twice (src/bvh.rs:114-116).
+    ConstantMedium::hit draws a fresh random number on every call (src/constant_medium.rs:91), so the second call, with t_max
+    already shortened to the first call's hit, gets a second chance to scatter earlier: the free path behaves as if the density
+    were doubled.  Oracle and device reproduce that with a draw slot per visit."""
+    hs, os_ = make_pair(rtamd, oracle, "final-scene", earth=earth_rgb, bvh_seed=13)
+    objs, nodes = hs.objects(), hs.nodes()
+    twins = [~int(n["left"]) for n in nodes if n["left"] < 0 and n["left"] == n["right"]]
+    fog = [o for o in twins if int(objs[o]["flags"]) & 4]
+    assert len(fog) == 1 and int(objs[fog[0]]["obj_id"]) == 6
+    gpu.upload(hs)
+    # rays that start inside the ball (centre (360,150,145), radius 70): from outside, the glass sphere that is the fog's boundary
+    # is also an object of its own and always the closer hit
+    rng = np.random.default_rng(99)
+    n = 100_000
+    rays = random_rays(rng, n, (150, 20, -200), (600, 400, 500))
+    inside = rng.normal(size=(n, 3))
+    inside *= (60.0 * rng.uniform(0, 1, size=(n, 1)) ** (1 / 3)) / np.linalg.norm(inside, axis=1, keepdims=True)
+    half = n // 2
+    rays["o"][:half] = np.array([360.0, 150.0, 145.0]) + inside[:half]
+    oh = os_.first_hit(rays, seed=4, precision=1)
+    gh = gpu.trace_batch(rays, precision=rtamd.F64, seed=4)
+    in_fog = oh["obj"] == 6
+    assert in_fog.mean() > 0.2, in_fog.mean()
+    frac, t_err, p_err, n_err, ok = compare(gh, oh, 1e-11, True, "final-scene, seed 13")
+    assert dist_err(rays, gh, oh, ok).max() < 1e-11
+    # the doubling itself, against the same scene with the usual seed (no medium in a one-object node): distance from the ray's
+    # origin to the scattering point, in world units; the fog has density 0.2, i.e. a mean free path of 5 - or 2.5 when doubled.
+    _, os7 = make_pair(rtamd, oracle, "final-scene", earth=earth_rgb)
+    oh7 = os7.first_hit(rays, seed=4, precision=1)
+
+    def mean_path(h):
+        m = h["obj"] == 6
+        return np.linalg.norm(h["p"][m] - rays["o"][m], axis=1).mean(), m.sum()
+
+    d13, n13 = mean_path(oh)
+    d7, n7 = mean_path(oh7)
+    print("\nmean free path inside the ball: one-object node %.3f (%d hits), ordinary leaf %.3f (%d hits)" % (d13, n13, d7, n7))
+    assert 4.5 < d7 < 5.5 and 2.2 < d13 < 2.8
+    # single precision walks a tree of its own: the medium's two visits must both be in it
+    gh32 = gpu.trace_batch(rays, precision=rtamd.F32, seed=4, as_rendered=True)
+    # half of these rays start inside a fog with a free path of 2.5: a free path that ends within 1e-4 of the ball's surface is a
+    # near tie with the glass, and there are many more of those here than among rays of a render
+    check_f32("final-scene", hs, os_, gh32, rays, oh, 4, rng, camera=False, max_excluded=0.02)
+
+
+def test_medium_over_a_nested_tree_f32_matches_f64(gpu, rtamd, earth_rgb):
+    """ConstantMedium(Translate(RotateY(BVH))) is inside the grammar the C ABI accepts; no scene of the reference has it.  The
+    sphere cluster of final-scene is turned into a fog with that boundary; the single-precision walk (deferred records, its own
+    tree) must report what the double-precision walk (the reference's recursion, checked against the oracle elsewhere) does."""
+    from custom_scene import EditedScene
+    base = rtamd.Scene("final-scene", earth=earth_rgb)
+    sc = EditedScene(rtamd, base)
+    holder = [i for i, o in enumerate(sc.objects) if (int(o["flags"]) & 8) and (int(o["flags"]) & 3) == 3]
+    assert len(holder) == 1
+    iso = [i for i, m in enumerate(sc.materials) if int(m["tag"]) == 4]
+    h = holder[0]
+    sc.objects["flags"][h] |= 4
+    sc.objects["medium_material"][h] = iso[0]
+    sc.objects["neg_inv_density"][h] = -1.0 / 0.02
+    gpu.upload(sc)
+    rng = np.random.default_rng(5)
+    n = 100_000
+    rays = random_rays(rng, n, (-300, 120, -600), (600, 540, 600))
+    target = np.array([-100.0 + 82, 270.0 + 82, 395.0 + 82]) + rng.uniform(-80, 80, size=(n, 3))  # the cluster: 165-cube at (-100,270,395), rotated
+    d = target - rays["o"]
+    rays["d"] = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.5, 8.0, size=(n, 1))
+    a = gpu.trace_batch(rays, precision=rtamd.F64, seed=6)
+    b = gpu.trace_batch(rays, precision=rtamd.F32, seed=6, as_rendered=True)
+    fog = a["obj"] == int(sc.objects["obj_id"][h])
+    assert fog.mean() > 0.05 and (a["material"][fog] == iso[0]).all(), fog.mean()
+    same = np.ones(n, dtype=bool)
+    for f in ("hit", "obj", "material"):
+        same &= a[f] == b[f]
+    # a free path ends where -ln(U)/density runs out: rays whose path ends within 1e-4 of the far boundary flip between fog and
+    # what lies behind it; everything else must agree
+    assert same.mean() > 0.999, same.mean()
+    both = same & fog
+    t_err = np.abs(a["t"][both] - b["t"][both]) * np.linalg.norm(rays["d"][both], axis=1) / 600.0
+    assert np.quantile(t_err, 0.999) < 1e-5, (np.quantile(t_err, 0.999), t_err.max())

@@ -203,6 +203,17 @@ def test_cornell_matches_reference_sample_render(oracle):
     assert 6.0 < cnt["rays"] / cnt["camera_rays"] < 7.5
 
 
+@pytest.mark.parametrize("name,spp", [("earth", 32), ("two-perlin-spheres", 32), ("simple-light", 128), ("random", 16)])
+def test_oracle_matches_reference_sample_renders(oracle, earth_rgb, name, spp):
+    """The oracle at the sample renders' framing (400x225; random.png is the same frame at 1920x1080) against the statistics of
+    earth.jpg, perlin.png, simple_light.png and random.png; what each image pins, and how loosely, is stated in golden_stats.py."""
+    import golden_stats
+    s = oracle.OracleScene(name, width=400, aspect=16 / 9, spp=spp, earth=earth_rgb if name == "earth" else None)
+    assert (s.width, s.height) == (400, 225)
+    acc, _, _ = s.render(0, spp, seed=17)
+    golden_stats.check(name, oracle.resolve(acc, spp))
+
+
 def test_oracle_sample_range_additivity(oracle):
     s = oracle.OracleScene("cornell-box", width=48, spp=6)
     whole, _, _ = s.render(0, 6, seed=3)
