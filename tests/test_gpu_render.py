@@ -18,8 +18,10 @@ pytestmark = pytest.mark.gpu
 
 # Scenes whose paths bounce between many small spheres: a last-bit difference (the device's log/sin/acos are ocml's, the oracle's
 # glibc's) is amplified by every such bounce, so a few paths in 10^5 part from the oracle's after half a dozen vertices.  These
-# scenes get a small allowance of differing paths; everywhere else the comparison is exact.
-CHAOTIC = {"final-scene": 1e-3, "random": 1e-3}
+# scenes get a small allowance of differing paths; everywhere else the comparison is exact.  Measured: 0 of 60 000 samples of
+# either scene differ (rate below 2e-5; tools/find_divergence.py found single cases in 10^5 on larger batches): the allowance
+# is 1e-4.
+CHAOTIC = {"final-scene": 1e-4, "random": 1e-4}
 
 SMALL = {  # width, spp for the full-frame comparisons (sized so the oracle finishes in seconds)
     "random": (160, 4), "two-spheres": (200, 8), "two-perlin-spheres": (200, 8), "earth": (200, 8),
@@ -32,7 +34,7 @@ def test_per_sample_radiance_f64(gpu, rtamd, oracle, earth_rgb, name):
     hs, os_ = make_pair(rtamd, oracle, name, earth=earth_rgb)
     gpu.upload(hs)
     rng = np.random.default_rng(3)
-    n = 20_000 if name not in ("final-scene", "random") else 6_000
+    n = 20_000 if name not in ("final-scene", "random") else 60_000
     pixel = rng.integers(0, hs.width * hs.height, size=n).astype(np.uint32)
     sample = rng.integers(0, 64, size=n).astype(np.uint32)
     want = os_.sample_radiance(21, pixel, sample)
@@ -40,6 +42,7 @@ def test_per_sample_radiance_f64(gpu, rtamd, oracle, earth_rgb, name):
     err = np.abs(got[:, :3] - want[:, :3]) / (np.abs(want[:, :3]) + 1e-3)
     # radiance and the number of closest-hit queries of every path (a path that parts from the oracle's usually still ends in black)
     bad = (err > 1e-9).any(axis=1) | (got[:, 3] != want[:, 3])
+    print("\n%s: %d of %d samples differ from the oracle (rate %.2e)" % (name, bad.sum(), n, bad.mean()))
     assert bad.sum() <= CHAOTIC.get(name, 0.0) * n, "%s: %d of %d samples differ, worst %g" % (name, bad.sum(), n, err.max())
 
 
