@@ -78,6 +78,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=96, help="samples per pixel of the bounded CPU sample")
     ap.add_argument("--save", default="", help="rank 0 writes the last image of the headline precision here (.png/.ppm)")
+    ap.add_argument("--reduce", choices=["lib", "torch"], default="lib",
+                    help="lib = the library's own rt_reduce_accum (RCCL communicator created through rt_comm_init, its id broadcast by "
+                         "torch.distributed); torch = torch.distributed.reduce.  lib falls back to torch when the communicator cannot be made")
+    ap.add_argument("--dump-accum", default="", help="rank 0 writes the headline precision's summed radiance (H x W x 3 float64, .npy) here")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the multi-rank path on a box with fewer GPUs than ranks (sums travel through host memory)")
     args = ap.parse_args()
@@ -121,6 +125,23 @@ def main():
     t_upload = time.perf_counter() - t_upload
     s0 = rank * args.spp // world
     s1 = (rank + 1) * args.spp // world
+    # N > 1: the sums travel through the library's own communicator (rt_comm_init / rt_reduce_accum, RCCL over xGMI); the id that
+    # rank 0 creates reaches the other ranks through torch.distributed, which also provides the barriers of the timing contract
+    lib_reduce = False
+    if dist is not None and args.backend == "nccl" and args.reduce == "lib":
+        ok = 1
+        try:
+            box = [rtamd.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ctx.comm_init(box[0], world, rank)
+        except Exception as e:  # noqa: BLE001 - any failure means: use torch's reduce instead, on every rank
+            ok = 0
+            print("rank %d: rt_comm_init failed (%s); falling back to torch.distributed.reduce" % (rank, e), file=sys.stderr, flush=True)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        lib_reduce = bool(flag.item())
+        if not lib_reduce and ok:
+            ctx.comm_destroy()
     rgb_host = torch.zeros((H, W, 3), dtype=torch.uint8).pin_memory().numpy() if rank == 0 else None  # page-locked: the copy is one DMA
     persistent = args.pipeline in ("auto", "persistent")
 
@@ -145,7 +166,9 @@ def main():
             torch.cuda.synchronize()  # the library renders on its own stream
             st = ctx.render_accum(accum.data_ptr(), s0, s1, precision=prec, pipeline=pipe, samples_per_pass=args.samples_per_pass)
             t_b = time.perf_counter()
-            if dist is not None:
+            if dist is not None and lib_reduce:
+                ctx.reduce_accum(accum.data_ptr(), W, H, precision=prec, root=0)  # W*H*3 values, once per frame, stream idle on return
+            elif dist is not None:
                 packed.copy_(accum.view(-1, 4)[:, :3].reshape(-1))
                 if args.backend == "nccl":
                     dist.reduce(packed, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: W*H*3 values, once per frame
@@ -263,6 +286,7 @@ def main():
                        "scene_build_s": t_scene, "upload_s": t_upload},
         }
         if world > 1:
+            out["config"]["reduce"] = "rt_reduce_accum (RCCL)" if lib_reduce else ("torch.distributed.reduce (%s)" % args.backend)
             out["per_rank_ms"] = {"columns": ["kernel", "render_call", "reduce", "resolve_and_copy"], "ranks": head["per_rank"]}
         cpu = None
         cnt = None
@@ -320,6 +344,8 @@ def main():
         print(json.dumps(out), flush=True)
         if args.save and head["rgb"] is not None:
             rtamd.save_image(args.save, head["rgb"])
+        if args.dump_accum:
+            np.save(args.dump_accum, head["accum"].view(H, W, 4)[:, :, :3].double().cpu().numpy())
     ctx.close()
     if dist is not None:
         dist.barrier()

@@ -16,8 +16,8 @@
  * device pointer.  No function falls back to a CPU path: without a usable HIP
  * device rt_create() fails.
  * A context serves one host thread at a time and drives one GPU (one process
- * per GPU; cross-GPU reduction of accumulation buffers is the caller's job,
- * see rt_render_accum()).
+ * or thread per GPU; rt_comm_init() / rt_reduce_accum() sum the GPUs'
+ * accumulation buffers onto one of them).
  */
 #ifndef RTAMD_H
 #define RTAMD_H
@@ -211,6 +211,24 @@ int rt_read_accum(rt_context* ctx, const void* accum_dev, uint32_t width, uint32
 /* render() of src/render.rs:179-207: rt_render_accum into the context's buffer + rt_resolve.
  * `accum_out` (optional) receives the width*height*3 linear sums as doubles. */
 int rt_render(rt_context* ctx, const rt_render_params* params, uint8_t* rgb8_out, double* accum_out, rt_stats* stats);
+
+/* ---- multi-GPU: one context per GPU (one process or thread each), sums reduced onto one rank over RCCL / xGMI ----
+ * The reference partitions image rows over worker threads (src/render.rs:218-224) and gathers pixels through an mpsc channel
+ * (src/render.rs:185,192-201).  Here every rank renders its slice of the SAMPLE range of the whole frame with rt_render_accum
+ * (streams are keyed by the global sample index, so the image does not depend on the number of ranks beyond summation order),
+ * then rt_reduce_accum sums the buffers onto `root`, which calls rt_resolve.  RCCL is opened at run time; without it these
+ * calls return RT_E_UNSUPPORTED and everything else keeps working. */
+typedef struct rt_comm_id { char bytes[128]; } rt_comm_id; /* = ncclUniqueId */
+/* Rank 0 creates the id; the host hands its 128 bytes to the other ranks by whatever channel it has (file, pipe, MPI, ...). */
+int rt_comm_unique_id(rt_comm_id* id);
+/* Collective over the n_ranks contexts that share `id`: joins this context's GPU to the communicator (ncclCommInitRank). */
+int rt_comm_init(rt_context* ctx, const rt_comm_id* id, int n_ranks, int rank);
+int rt_comm_destroy(rt_context* ctx);
+/* Collective: element-wise sum of the ranks' accumulation buffers (DEVICE, width*height*4 floats or doubles as rt_render_accum
+ * fills them; NULL = the context's own) onto rank `root`.  One ncclReduce(sum) of width*height*3 values - the unused fourth
+ * value of a pixel's slot does not travel - on the context's stream; returns with the stream idle.  The other ranks' buffers
+ * are left unchanged. */
+int rt_reduce_accum(rt_context* ctx, void* accum_dev, uint32_t width, uint32_t height, int precision, int root);
 
 /* rt_render() for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid
  * hipMalloc.  No counterpart in the reference (its render() allocates freely); it exists for those callers only.

@@ -76,6 +76,11 @@ struct rt_context {
   size_t accum_bytes = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   unsigned long long* h_rays = nullptr;  // one page-locked host word: where the allocation-free entry point receives its ray count
+  // multi-GPU (comm.hip): RCCL communicator this context's GPU belongs to, its rank, and the packed W*H*3 staging buffer
+  void* comm = nullptr;
+  int comm_rank = 0, comm_size = 1;
+  void* comm_buf = nullptr;
+  size_t comm_buf_bytes = 0;
   void* scratch = nullptr;               // this device's address of the library's static scratch array (see rtamd_api.hip)
 };
 

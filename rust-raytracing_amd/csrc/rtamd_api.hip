@@ -218,6 +218,7 @@ void rt_destroy(rt_context* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm) (void)rt_comm_destroy(c);
   free_scene(c);
   if (c->ws) (void)hipFree(c->ws);
   if (c->accum) (void)hipFree(c->accum);

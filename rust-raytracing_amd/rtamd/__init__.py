@@ -28,6 +28,7 @@ SCENES = {
 
 # every symbol include/rtamd.h and include/rtamd_host.h declare
 ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_upload_scene", "rt_render_accum", "rt_resolve", "rt_read_accum", "rt_render", "rt_render_noalloc",
+               "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_reduce_accum",
                "rt_trace_batch", "rt_camera_rays", "rt_sample_radiance", "rt_sample_path", "rt_last_error", "rt_version"]
 HOST_ABI_SYMBOLS = ["rth_scene_create", "rth_scene_destroy", "rth_scene_desc", "rth_scene_config", "rth_scene_from_name",
                     "rth_scene_name", "rth_save_image", "rth_load_ppm", "rth_free", "rth_render_and_save", "rth_last_error"]
@@ -110,6 +111,10 @@ def load_libraries():
     L.rt_read_accum.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_int, vp]
     L.rt_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
     L.rt_render_noalloc.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
+    L.rt_comm_unique_id.argtypes = [vp]
+    L.rt_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.rt_comm_destroy.argtypes = [vp]
+    L.rt_reduce_accum.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
     L.rt_trace_batch.argtypes = [vp, vp, C.c_size_t, vp, C.c_int, C.c_uint64]
     L.rt_camera_rays.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, C.c_size_t, C.c_uint64, C.c_int, vp]
     L.rt_sample_radiance.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, C.c_size_t, C.c_uint64, C.c_int, vp]
@@ -272,6 +277,18 @@ class Context:
         _check(self.L.rt_render_noalloc(self.h, C.byref(p), C.c_void_p(accum_dev_ptr), _p(rgb_out), C.byref(st)))
         return st.as_dict()
 
+    def comm_init(self, comm_id, n_ranks, rank):
+        """rt_comm_init: joins this context's GPU to the communicator identified by the 128 bytes of `comm_id`."""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(comm_id))
+        _check(self.L.rt_comm_init(self.h, C.byref(buf), n_ranks, rank))
+
+    def comm_destroy(self):
+        _check(self.L.rt_comm_destroy(self.h))
+
+    def reduce_accum(self, accum_dev_ptr, width, height, precision=F32, root=0):
+        """rt_reduce_accum: sums the ranks' DEVICE buffers (address as int, or None for the context's own) onto `root`."""
+        _check(self.L.rt_reduce_accum(self.h, C.c_void_p(accum_dev_ptr) if accum_dev_ptr else None, width, height, precision, root))
+
     def resolve(self, accum_dev_ptr, width, height, spp, precision=F32, out=None):
         """rt_resolve; `out` (uint8 [height, width, 3], e.g. a view of pinned memory) is filled in place when given."""
         rgb = out if out is not None else np.zeros((height, width, 3), dtype=np.uint8)
@@ -317,6 +334,14 @@ class Context:
                                      depth if depth is not None else self.scene.depth, _p(pixel), _p(sample), n, seed, precision,
                                      max_vertices, _p(out)))
         return out[:n * 4].reshape(n, 4), out[n * 4:].reshape(n, max_vertices, 12)
+
+
+def comm_unique_id():
+    """rt_comm_unique_id: the 128 bytes rank 0 hands to the other ranks."""
+    L, _ = load_libraries()
+    buf = (C.c_char * 128)()
+    _check(L.rt_comm_unique_id(C.byref(buf)))
+    return bytes(buf.raw)
 
 
 def save_image(path, rgb):
