@@ -219,10 +219,15 @@ def main():
             allr = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(allr, mine)
             per_rank = [[round(float(x), 3) for x in a.tolist()] for a in allr]
-        return {"name": name, "elapsed": elapsed_max, "rays": rays, "rays_all": rays_all, "kernel_ms": kernel_ms, "launches": launches,
+        # per-lane walks of trees that do not fit on chip: what a closest-hit query costs on the tree THIS precision walks (the f64
+        # kernels walk the reference's tree, the f32 kernels the library's own), measured on the device over the rays of 8192 paths
+        walk = None
+        if rank == 0 and stats and stats[-1]["scene_in_lds"] in (4, 6, 8):
+            walk = ctx.walk_cost(prec, n_paths=8192, seed=1)
+        return {"name": name, "walk": walk, "elapsed": elapsed_max, "rays": rays, "rays_all": rays_all, "kernel_ms": kernel_ms, "launches": launches,
                 "stats": stats, "rgb": None if rgb is None else rgb.copy(), "accum": accum, "split": split, "per_rank": per_rank}
 
-    def roofline_of(leg, fpr, tree_bytes_per_ray=None):
+    def roofline_of(leg, fpr):
         name = leg["name"]
         if fpr is None or leg["kernel_ms"] <= 0:
             return None
@@ -253,20 +258,23 @@ def main():
                   else ("k_bounce_fused" if args.pipeline == "fused" else "k_trace+k_shade"))
         secs = leg["kernel_ms"] * 1e-3
         valu = {"bound": "valu", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "flops_per_ray": fpr}
-        # Scenes whose tree does not fit on chip (only its top levels are staged in LDS): the walk is bound by the memory system.
-        # Algorithmic bytes: 32 per tree node visited and per primitive tested (event counts of the oracle on the reference's
-        # tree over a sample of the same frame) plus the radiance sums.
-        in_memory = stats[-1]["scene_in_lds"] in (4, 6, 8) and tree_bytes_per_ray is not None
-        bpr = (tree_bytes_per_ray + qb) if in_memory else qb
+        # Scenes whose tree does not fit on chip (only its top levels are staged in LDS): the walk is priced against the memory
+        # system.  Algorithmic bytes: 32 per tree node visited and per primitive tested - counted on the device, on the tree this
+        # precision's kernels walk, over the rays of a sample of the frame's paths - plus the radiance sums.
+        in_memory = leg["walk"] is not None
+        bpr = (32.0 * (leg["walk"][0] + leg["walk"][1]) + qb) if in_memory else qb
         hbm = {"bound": "hbm", "achieved": bpr * leg["rays"] / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": bpr * leg["rays"] / secs / 1e9 / HBM_PEAK_GBS, "bytes_per_ray": bpr}
         main, other = (hbm, valu) if in_memory else (valu, hbm)
         out = dict(main)
+        if in_memory:
+            out["walk"] = {"box_tests_per_ray": leg["walk"][0], "leaf_tests_per_ray": leg["walk"][1], "rays_sampled": leg["walk"][2]}
         out.update({
             "traffic": traffic, "kernel": kernel, "avg_launch_ms": leg["kernel_ms"] / max(1.0, leg["launches"]), "launches": leg["launches"],
             "issue": issue,
-            "note": ("the tree (tens of MB) lives in HBM / L2 / Infinity Cache and every lane fetches its own nodes: the memory system bounds the "
-                     "walk; valu = the same launches against the vector-ALU roofline" if in_memory else
+            "note": ("the tree (tens of MB) lives in HBM / L2 / Infinity Cache and every lane fetches its own nodes: priced against the HBM "
+                     "roofline in algorithmic bytes (a rate above what `traffic` shows reaching HBM is served by the caches); valu = the same "
+                     "launches against the vector-ALU roofline" if in_memory else
                      "no dense contraction on this path (MFMA unused by design) and the scene is cache resident, so the vector ALU bounds it; "
                      "peak is the vector FMA peak of the dtype; hbm = the same launches against the HBM roofline"),
             ("valu" if in_memory else "hbm"): other,
@@ -329,11 +337,7 @@ def main():
                     fpr = json.load(f).get(args.scene)
             except OSError:
                 fpr = None
-        tree_bpr = None
-        if cnt:
-            tests = sum(cnt[k] for k in ("aabb", "sphere_miss", "sphere_hit", "moving_miss", "moving_hit", "rect_miss", "rect_hit"))
-            tree_bpr = 32.0 * tests / max(1, cnt["rays"])
-        out["roofline"] = roofline_of(head, fpr, tree_bpr)
+        out["roofline"] = roofline_of(head, fpr)
         if side is not None:
             # error of the f32 frame against the f64 frame of this run, both at the full sample count: linear radiance per pixel
             # (sum / spp) clamped to [0, 1] as color_to_rgb does before its gamma (src/color.rs:20-25)
@@ -344,7 +348,7 @@ def main():
             out["f32"] = {
                 "value": side["rays_all"] / side["elapsed"] / 1e6, "unit": "Mrays/s", "dtype": "f32",
                 "ms_per_step": 1e3 * side["elapsed"] / max(1, args.steps), "steps": args.steps, "warmup": args.warmup,
-                "roofline": roofline_of(side, fpr, tree_bpr),
+                "roofline": roofline_of(side, fpr),
                 "image_error_vs_f64": {
                     "samples_per_pixel": args.spp,
                     "mean_f64": [float(x) for x in m64], "mean_f32": [float(x) for x in m32],

@@ -253,6 +253,9 @@ typedef struct rt_hit { /* HitRecord, src/hittable.rs:10-18 */
 /* `precision` may carry RT_TRACE_AS_RENDERED: the records are then built by exactly the code the render kernels run for this
  * scene, which fills (u, v) only when one of the scene's textures reads them (they are reported as 0 otherwise). */
 #define RT_TRACE_AS_RENDERED 0x100
+/* RT_TRACE_VISITS (implies AS_RENDERED): u and v of every record report instead the number of box entries and the number of
+ * leaves the walk tested for the ray - the work a closest-hit query costs on the tree the kernels of `precision` walk. */
+#define RT_TRACE_VISITS 0x200
 int rt_trace_batch(rt_context* ctx, const rt_ray* rays, size_t n, rt_hit* hits, int precision, uint64_t seed);
 
 /* Primary rays exactly as the sample loop builds them (src/render.rs:230-234 + src/camera.rs:62-72). */

@@ -114,7 +114,7 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
 template <class R>
 int render_accum_impl(rt_context* c, const rt_render_params& p, void* accum_dev, rt_stats* stats, unsigned long long* counters_override = nullptr,
                       unsigned long long* host_rays = nullptr);
-template <class R> int trace_batch_impl(rt_context* c, const rt_ray* rays, size_t n, rt_hit* hits, uint64_t seed, bool as_rendered);
+template <class R> int trace_batch_impl(rt_context* c, const rt_ray* rays, size_t n, rt_hit* hits, uint64_t seed, int mode);
 template <class R>
 int pairs_kernel_impl(rt_context* c, int which, uint32_t W, uint32_t H, uint32_t max_depth, const uint32_t* pixel, const uint32_t* sample, size_t n,
                       uint64_t seed, void* out, size_t out_bytes);

@@ -68,8 +68,10 @@ template <class R> RT_DEV V3<R> operator-(V3<R> v) { return V3<R>(-v.x, -v.y, -v
 template <class R> RT_DEV R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          // src/vec3.rs:58-60
 template <class R> RT_DEV R length_squared(V3<R> v) { return v.x * v.x + v.y * v.y + v.z * v.z; }         // src/vec3.rs:49-51
 template <class R> RT_DEV R length(V3<R> v) { return rt_sqrt(length_squared(v)); }                        // src/vec3.rs:45-47
-template <class R> RT_DEV V3<R> vdiv(V3<R> v, R f) { return ((R)1 / f) * v; }                             // src/vec3.rs:224-230
-template <class R> RT_DEV V3<R> unit_vector(V3<R> v) { return vdiv(v, length(v)); }                       // src/vec3.rs:77-79
+RT_DEV V3<double> vdiv(V3<double> v, double f) { return (1.0 / f) * v; }                                  // src/vec3.rs:224-230
+RT_DEV V3<float> vdiv(V3<float> v, float f) { return __builtin_amdgcn_rcpf(f) * v; }                      // hardware reciprocal (1 ulp)
+RT_DEV V3<double> unit_vector(V3<double> v) { return vdiv(v, length(v)); }                                // src/vec3.rs:77-79
+RT_DEV V3<float> unit_vector(V3<float> v) { return __builtin_amdgcn_rsqf(length_squared(v)) * v; }        // hardware 1/sqrt (1 ulp)
 template <class R> RT_DEV bool near_zero(V3<R> v) {                                                       // src/vec3.rs:53-56
   const R s = (R)1e-8;
   return rt_abs(v.x) < s && rt_abs(v.y) < s && rt_abs(v.z) < s;

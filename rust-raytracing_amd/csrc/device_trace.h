@@ -59,6 +59,12 @@ struct Origin {
   RT_DEV int leaf() const { return (int)(bits >> 3) - 1; }
   RT_DEV int side() const { return (int)(bits & 7u) - 1; }
 };
+// Diagnostic tally of one closest-hit query on a per-lane walk: box entries tested and leaves tested (what the memory roofline
+// of the large-scene kernels is priced in).  Only the inspection kernel's counting variant passes one; everywhere else the
+// pointer is a compile-time null and the increments vanish.
+struct Visits {
+  uint32_t boxes = 0, leaves = 0;
+};
 template <class R> struct Guard { static constexpr bool on = false; };
 template <> struct Guard<float> { static constexpr bool on = true; };
 
@@ -167,9 +173,13 @@ RT_DEV bool rect_hit(R a0, R a1, R b0, R b1, R k, int material, const Ray<R>& ra
   return true;
 }
 
-template <class R> RT_DEV V3<R> moving_center(const DShape<R>& s, R time) {  // src/moving_sphere.rs:37-40
-  V3<R> c0(s.p[0], s.p[1], s.p[2]), c1(s.p[3], s.p[4], s.p[5]);
+RT_DEV V3<double> moving_center(const DShape<double>& s, double time) {  // src/moving_sphere.rs:37-40
+  V3<double> c0(s.p[0], s.p[1], s.p[2]), c1(s.p[3], s.p[4], s.p[5]);
   return c0 + ((time - s.p[7]) / (s.p[8] - s.p[7])) * (c1 - c0);
+}
+RT_DEV V3<float> moving_center(const DShape<float>& s, float time) {  // the quotient by the hardware reciprocal (1 ulp)
+  V3<float> c0(s.p[0], s.p[1], s.p[2]), c1(s.p[3], s.p[4], s.p[5]);
+  return c0 + ((time - s.p[7]) * __builtin_amdgcn_rcpf(s.p[8] - s.p[7])) * (c1 - c0);
 }
 
 // `self_side`: -2 when the ray does not start on this object, otherwise the side it starts on (-1 for one-sided shapes).
@@ -230,7 +240,7 @@ template <class R, class C> RT_DEV bool shape_hit(const DShape<R>& s, int leaf, 
 
 template <class R, class C, int LEVEL>
 RT_DEV bool traverse_lane(const SceneView<R, C>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org,
-                          uint32_t visit = 0u);
+                          uint32_t visit = 0u, Visits* tally = nullptr);
 
 // [Translate(] [RotateY(] geometry [))] — the part of an object below an optional ConstantMedium.
 template <class R, class C, int LEVEL>
@@ -357,7 +367,7 @@ template <> struct LaneBoxTest<float> {
 
 template <class R, class C, int LEVEL>
 RT_DEV bool traverse_lane(const SceneView<R, C>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org,
-                          uint32_t visit) {
+                          uint32_t visit, Visits* tally) {
   const LaneBoxTest<R> box(ray);
   R closest = t_max;
   bool any = false;
@@ -367,11 +377,13 @@ RT_DEV bool traverse_lane(const SceneView<R, C>& sv, int start, const Ray<R>& ra
     // Box entries first, until every lane of the wave stands on a leaf (or has left the tree): the leaf code below is then
     // entered by the lanes together instead of once per lane that happens to reach a leaf.
     while (!(lk.hit & LEAF_FLAG)) {
+      if (tally) ++tally->boxes;
       i = box.hit(lk, ray, t_min, closest) ? (int)lk.hit : lk.miss;
       if (i < 0) break;
       lk = sv.link(i);
     }
     if (i < 0) break;
+    if (tally) ++tally->leaves;
     if (leaf_hit<R, C, LEVEL>(sv, lk.hit, ray, t_min, closest, rec, media, org, visit)) { closest = rec.t; any = true; }
     i = lk.miss;
   }

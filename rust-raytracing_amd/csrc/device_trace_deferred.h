@@ -511,7 +511,7 @@ RT_DEV bool traverse_flat(const SceneView<R, C>& sv, int start, const Ray<R>& ra
 // the double-precision kernels, which are the ones compared field by field, keep the eager walk.)
 template <class C>
 RT_DEV bool traverse_lane_deferred(const SceneView<float, C>& sv, int start, const Ray<float>& ray, float t_min, float t_max, Rec<float>& rec,
-                                   Stream& media, Origin org) {
+                                   Stream& media, Origin org, Visits* tally = nullptr) {
   const LaneBoxTest<float> box(ray);
   RayInv<float> ri(ray.d);
   ri.inv = box.inv;
@@ -521,11 +521,13 @@ RT_DEV bool traverse_lane_deferred(const SceneView<float, C>& sv, int start, con
   while (i >= 0) {
     DLink<float> lk = sv.link(i);
     while (!(lk.hit & LEAF_FLAG)) {
+      if (tally) ++tally->boxes;
       i = box.hit(lk, ray, t_min, closest) ? (int)lk.hit : lk.miss;
       if (i < 0) break;
       lk = sv.link(i);
     }
     if (i < 0) break;
+    if (tally) ++tally->leaves;
     const int obj = (int)(lk.hit & LEAF_INDEX_MASK);
     bool nested = false;
     if constexpr (C::has(F_NESTED)) {
@@ -544,11 +546,13 @@ RT_DEV bool traverse_lane_deferred(const SceneView<float, C>& sv, int start, con
           while (j >= 0) {
             DLink<float> nl = sv.link(j);
             while (!(nl.hit & LEAF_FLAG)) {
+              if (tally) ++tally->boxes;
               j = lbox.hit(nl, local, lo, hi) ? (int)nl.hit : nl.miss;
               if (j < 0) break;
               nl = sv.link(j);
             }
             if (j < 0) break;
+            if (tally) ++tally->leaves;
             float t;
             int side;
             if (leaf_t<float, C>(sv, nl.hit, local, rl, lo, hi, media, from, t, side, visit_bit(lk.hit, 0) | visit_bit(nl.hit, 1))) {
@@ -643,12 +647,14 @@ RT_DEV bool traverse_lane_deferred(const SceneView<float, C>& sv, int start, con
 
 // world.hit(ray, t_min, t_max, rec).  May be called from divergent code: lanes without a ray simply do not take part.
 template <class R, class C>
-RT_DEV bool closest_hit(const SceneView<R, C>& sv, int root, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
+RT_DEV bool closest_hit(const SceneView<R, C>& sv, int root, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org,
+                        Visits* tally = nullptr) {
   if constexpr (C::walk == WALK_UNIFORM) {
+    if (tally) tally->leaves += sv.n_flat + sv.n_frect[0] + sv.n_frect[1] + sv.n_frect[2];  // every leaf, no box
     return traverse_flat<R, C>(sv, root, ray, t_min, t_max, rec, media, org);
   } else {
-    if constexpr (sizeof(R) == sizeof(float)) return traverse_lane_deferred<C>(sv, root, ray, t_min, t_max, rec, media, org);
-    else return traverse_lane<R, C, 0>(sv, root, ray, t_min, t_max, rec, media, org);
+    if constexpr (sizeof(R) == sizeof(float)) return traverse_lane_deferred<C>(sv, root, ray, t_min, t_max, rec, media, org, tally);
+    else return traverse_lane<R, C, 0>(sv, root, ray, t_min, t_max, rec, media, org, 0u, tally);
   }
 }
 

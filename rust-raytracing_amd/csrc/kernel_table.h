@@ -20,7 +20,7 @@ template <class R> struct KernelTable {
                 PathQueue<R> out, uint32_t* counters, uint32_t* cursors, const uint32_t* class_counters, const uint32_t* class_index, uint32_t capacity,
                 R* accum, uint32_t bounce);
   void (*first_hit)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const RayIO* rays, uint32_t n, HitIO* hits, uint64_t seed,
-                    bool as_rendered);
+                    int mode);
   void (*sample_radiance)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, uint32_t W, uint32_t H, uint32_t max_depth,
                           const uint32_t* pixel, const uint32_t* sample, uint32_t n, uint64_t seed, double* out, double* path_out, uint32_t max_vertices);
 };
@@ -81,9 +81,10 @@ template <class R, class C> KernelTable<R> make_table() {
                        capacity, accum, bounce);
   };
   t.first_hit = [](uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const RayIO* rays, uint32_t n, HitIO* hits, uint64_t seed,
-                   bool as_rendered) {
-    if (as_rendered) hipLaunchKernelGGL((k_first_hit<R, C, true>), dim3(grid), dim3(kBlockThreads), lds, st, sc, rays, n, hits, seed);
-    else hipLaunchKernelGGL((k_first_hit<R, C, false>), dim3(grid), dim3(kBlockThreads), lds, st, sc, rays, n, hits, seed);
+                   int mode) {
+    if (mode == 2) hipLaunchKernelGGL((k_first_hit<R, C, 2>), dim3(grid), dim3(kBlockThreads), lds, st, sc, rays, n, hits, seed);
+    else if (mode == 1) hipLaunchKernelGGL((k_first_hit<R, C, 1>), dim3(grid), dim3(kBlockThreads), lds, st, sc, rays, n, hits, seed);
+    else hipLaunchKernelGGL((k_first_hit<R, C, 0>), dim3(grid), dim3(kBlockThreads), lds, st, sc, rays, n, hits, seed);
   };
   t.sample_radiance = [](uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, uint32_t W, uint32_t H, uint32_t max_depth,
                          const uint32_t* pixel, const uint32_t* sample, uint32_t n, uint64_t seed, double* out, double* path_out,

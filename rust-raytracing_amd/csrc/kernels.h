@@ -393,6 +393,10 @@ constexpr uint32_t kStepThreads = RT_STEP_THREADS;
 #define RT_BOX_STEPS 4
 #define RT_TURNS 4
 #endif
+#ifndef RT_LEAF_LANES
+#define RT_LEAF_LANES 16
+#endif
+constexpr uint32_t kLeafLanes = RT_LEAF_LANES;
 constexpr uint32_t kRestartLanes = RT_RESTART_LANES;
 constexpr int kBoxStepsPerTurn = RT_BOX_STEPS;
 constexpr int kTurnsPerCheck = RT_TURNS;
@@ -478,7 +482,12 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
           if (i >= 0) lk = sv.link(i);
         }
       }
-      if (i >= 0 && (lk.hit & LEAF_FLAG)) {
+      // Leaves are tested when enough lanes stand on one (or no lane has a box to test): the leaf code is several times longer than
+      // a box step, and run for the one or two lanes that happen to have arrived it would cost as much as for a full wave.
+      const bool at_leaf = i >= 0 && (lk.hit & LEAF_FLAG);
+      const unsigned long long leaf_lanes = __ballot(at_leaf);
+      if ((uint32_t)__popcll(leaf_lanes) < kLeafLanes && __ballot(i >= 0 && !(lk.hit & LEAF_FLAG)) != 0ull) continue;
+      if (at_leaf) {
         Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
         if (leaf_hit<R, C, 0>(sv, lk.hit, st.ray, (R)0.001, closest, rec, media, st.org)) { closest = rec.t; any = true; }
         i = lk.miss;
@@ -622,11 +631,13 @@ struct HitIO {  // = rt_hit
   double t, p[3], n[3], u, v;
 };
 
-// AS_RENDERED = false: the inspection entry reports (u, v) whatever the scene's textures read.  true: the kernel configuration the
-// render kernels run, so that their record building is what gets inspected ((u, v) then stay 0 in scenes that never read them).
-template <class R, class C, bool AS_RENDERED>
+// MODE 0: the inspection entry reports (u, v) whatever the scene's textures read.  MODE 1 (as rendered): the kernel configuration
+// the render kernels run, so that their record building is what gets inspected ((u, v) then stay 0 in scenes that never read
+// them).  MODE 2: as rendered, and u, v report the numbers of box entries and of leaves the walk tested for the ray.
+template <class R, class C, int MODE>
 __global__ __launch_bounds__(256) void k_first_hit(DeviceScene<R> sc, const RayIO* rays, uint32_t n, HitIO* hits, uint64_t seed) {
   extern __shared__ __align__(16) uint8_t lds[];
+  constexpr bool AS_RENDERED = MODE != 0;
   using CU = Cfg<AS_RENDERED ? C::F : (C::F | F_UV), C::walk>;
   const SceneView<R, CU> sv = make_view<R, CU>(sc, lds);
   uint32_t stride = gridDim.x * blockDim.x;
@@ -638,7 +649,8 @@ __global__ __launch_bounds__(256) void k_first_hit(DeviceScene<R> sc, const RayI
     ray.time = (R)r.time;
     Stream media(seed, r.pixel, r.sample, r.bounce, STAGE_MEDIA);
     Rec<R> rec;
-    bool h = closest_hit<R, CU>(sv, sc.root_link, ray, (R)r.tmin, (R)r.tmax, rec, media, Origin());
+    Visits tally;
+    bool h = closest_hit<R, CU>(sv, sc.root_link, ray, (R)r.tmin, (R)r.tmax, rec, media, Origin(), MODE == 2 ? &tally : nullptr);
     HitIO o;
     o.hit = h ? 1 : 0;
     if (h) {
@@ -652,6 +664,7 @@ __global__ __launch_bounds__(256) void k_first_hit(DeviceScene<R> sc, const RayI
       o.t = o.u = o.v = 0.0;
       o.p[0] = o.p[1] = o.p[2] = o.n[0] = o.n[1] = o.n[2] = 0.0;
     }
+    if constexpr (MODE == 2) { o.u = (double)tally.boxes; o.v = (double)tally.leaves; }
     hits[i] = o;
   }
 }

@@ -197,7 +197,9 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
   d.images = c->d_images;
   d.n_images = s.n_images;
   d.root_link = root_link;
-  d.lds_links = (preset == PRESET_ALL_TOP || preset == PRESET_BALLS_TOP || preset == PRESET_FLATALL_TOP) ? std::min<uint32_t>(lay.n_links, kLdsTopMax / (uint32_t)sizeof(DLink<R>)) : 0u;
+  uint32_t top_bytes = kLdsTopMax;
+  if (const char* e = getenv("RTAMD_TOP_LDS_BYTES")) top_bytes = (uint32_t)std::max(0, atoi(e));  // measurement switch
+  d.lds_links = (preset == PRESET_ALL_TOP || preset == PRESET_BALLS_TOP || preset == PRESET_FLATALL_TOP) ? std::min<uint32_t>(lay.n_links, top_bytes / (uint32_t)sizeof(DLink<R>)) : 0u;
   im.lds_bytes = im.table.lds_bytes(lay, d.lds_links);
   auto v3 = [](const double* p) { return V3<R>((R)p[0], (R)p[1], (R)p[2]); };
   d.camera.origin = v3(s.camera.origin); d.camera.lower_left_corner = v3(s.camera.lower_left_corner);
@@ -423,7 +425,7 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
   return RT_OK;
 }
 
-template <class R> int trace_batch_impl(rt_context* c, const rt_ray* rays, size_t n, rt_hit* hits, uint64_t seed, bool as_rendered) {
+template <class R> int trace_batch_impl(rt_context* c, const rt_ray* rays, size_t n, rt_hit* hits, uint64_t seed, int mode) {
   SceneImage<R>& im = image_of<R>(c);
   RayIO* d_rays = nullptr;
   HitIO* d_hits = nullptr;
@@ -434,7 +436,7 @@ template <class R> int trace_batch_impl(rt_context* c, const rt_ray* rays, size_
   do {
     if (hipMemcpyAsync(d_rays, rays, n * sizeof(RayIO), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(RT_E_HIP, "H2D rays failed"); break; }
     uint32_t grid = grid_for(c, n, 8);
-    im.table.first_hit(grid, im.lds_bytes, c->stream, im.dev, d_rays, (uint32_t)n, d_hits, seed, as_rendered);
+    im.table.first_hit(grid, im.lds_bytes, c->stream, im.dev, d_rays, (uint32_t)n, d_hits, seed, mode);
     if (hipGetLastError() != hipSuccess) { rc = fail(RT_E_HIP, "k_first_hit launch failed"); break; }
     if (hipMemcpyAsync(hits, d_hits, n * sizeof(HitIO), hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail(RT_E_HIP, "D2H hits failed"); break; }
     if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(RT_E_HIP, "stream sync failed after k_first_hit"); break; }
@@ -494,7 +496,7 @@ template <class R> int resolve_impl(rt_context* c, const void* accum_dev, size_t
   template void layout_sections<R>(BlobLayout&);                                                                                        \
   template int build_image<R>(rt_context*, const rt_scene_desc&, const std::vector<TmpLink>&, int, const std::vector<int>&, int, SceneImage<R>&); \
   template int render_accum_impl<R>(rt_context*, const rt_render_params&, void*, rt_stats*, unsigned long long*, unsigned long long*);                                              \
-  template int trace_batch_impl<R>(rt_context*, const rt_ray*, size_t, rt_hit*, uint64_t, bool);                                                  \
+  template int trace_batch_impl<R>(rt_context*, const rt_ray*, size_t, rt_hit*, uint64_t, int);                                                   \
   template int pairs_kernel_impl<R>(rt_context*, int, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint32_t*, size_t, uint64_t, void*, \
                                     size_t);                                                                                               \
   template int resolve_impl<R>(rt_context*, const void*, size_t, uint32_t, uint8_t*);

@@ -526,12 +526,12 @@ int rt_trace_batch(rt_context* c, const rt_ray* rays, size_t n, rt_hit* hits, in
   if (n == 0) return RT_OK;
   if (!rays || !hits) return fail(RT_E_INVALID, "rays or hits is NULL");
   if (n > 0x7FFFFFFFull) return fail(RT_E_INVALID, "batch too large");
-  const bool as_rendered = (precision & RT_TRACE_AS_RENDERED) != 0;
-  precision &= ~RT_TRACE_AS_RENDERED;
+  const int mode = (precision & RT_TRACE_VISITS) ? 2 : ((precision & RT_TRACE_AS_RENDERED) ? 1 : 0);
+  precision &= ~(RT_TRACE_AS_RENDERED | RT_TRACE_VISITS);
   if (precision != RT_PRECISION_F32 && precision != RT_PRECISION_F64) return fail(RT_E_INVALID, "unknown precision");
   HIP_TRY(hipSetDevice(c->device));
-  return precision == RT_PRECISION_F64 ? trace_batch_impl<double>(c, rays, n, hits, seed, as_rendered)
-                                       : trace_batch_impl<float>(c, rays, n, hits, seed, as_rendered);
+  return precision == RT_PRECISION_F64 ? trace_batch_impl<double>(c, rays, n, hits, seed, mode)
+                                       : trace_batch_impl<float>(c, rays, n, hits, seed, mode);
 }
 
 int rt_camera_rays(rt_context* c, uint32_t width, uint32_t height, const uint32_t* pixel, const uint32_t* sample, size_t n, uint64_t seed,

@@ -19,6 +19,7 @@ HOST_LIB_PATH = os.path.join(BUILD_DIR, "librtamd_host.so")
 
 F32, F64 = 0, 1
 TRACE_AS_RENDERED = 0x100  # rt_trace_batch: records built by the render kernels' own configuration
+TRACE_VISITS = 0x200       # ... and u, v = box entries / leaves tested by the walk
 PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_SORTED, PIPELINE_PERSISTENT = 0, 1, 2, 3
 
 SCENES = {
@@ -301,11 +302,30 @@ class Context:
         _check(self.L.rt_read_accum(self.h, C.c_void_p(accum_dev_ptr) if accum_dev_ptr else None, width, height, precision, _p(out)))
         return out
 
-    def trace_batch(self, rays, precision=F64, seed=0, as_rendered=False):
+    def trace_batch(self, rays, precision=F64, seed=0, as_rendered=False, visits=False):
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
         hits = np.zeros(rays.size, dtype=HIT_DTYPE)
-        _check(self.L.rt_trace_batch(self.h, _p(rays), rays.size, _p(hits), precision | (TRACE_AS_RENDERED if as_rendered else 0), seed))
+        flags = (TRACE_AS_RENDERED if as_rendered else 0) | (TRACE_VISITS if visits else 0)
+        _check(self.L.rt_trace_batch(self.h, _p(rays), rays.size, _p(hits), precision | flags, seed))
         return hits
+
+    def walk_cost(self, precision, n_paths=8192, seed=0, max_vertices=8):
+        """Mean number of (box entries, leaves) a closest-hit query of a render tests on the tree the kernels of `precision` walk:
+        the rays of `n_paths` random paths of the uploaded scene's frame (their first max_vertices queries) traced once more with
+        RT_TRACE_VISITS."""
+        rng = np.random.default_rng(seed)
+        sc = self.scene
+        pixel = rng.integers(0, sc.width * sc.height, size=n_paths).astype(np.uint32)
+        sample = rng.integers(0, max(1, sc.spp), size=n_paths).astype(np.uint32)
+        _, verts = self.sample_path(pixel, sample, seed=seed, precision=precision, max_vertices=max_vertices)
+        v = verts.reshape(-1, 12)
+        used = (np.abs(v[:, 3:6]).sum(axis=1) > 0)  # unused records are zero
+        rays = np.zeros(int(used.sum()), dtype=RAY_DTYPE)
+        rays["o"], rays["d"] = v[used, 0:3], v[used, 3:6]
+        rays["time"] = rng.uniform(0, 1, size=rays.size)
+        rays["tmin"], rays["tmax"] = 0.001, np.inf
+        h = self.trace_batch(rays, precision=precision, seed=seed, visits=True)
+        return float(h["u"].mean()), float(h["v"].mean()), int(rays.size)
 
     def camera_rays(self, pixel, sample, seed=0, precision=F64, width=0, height=0):
         pixel = np.ascontiguousarray(pixel, dtype=np.uint32)
