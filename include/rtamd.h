@@ -212,6 +212,18 @@ int rt_read_accum(rt_context* ctx, const void* accum_dev, uint32_t width, uint32
  * `accum_out` (optional) receives the width*height*3 linear sums as doubles. */
 int rt_render(rt_context* ctx, const rt_render_params* params, uint8_t* rgb8_out, double* accum_out, rt_stats* stats);
 
+/* ---- progressive rendering: the polling side of ThreadedRenderer (src/render.rs:69-108) ----
+ * The GUI of the reference starts a render, then drains finished pixels once per UI frame (check_progress, src/render.rs:84-108)
+ * into an image it redraws.  Here the image refines as a whole: rt_progress_begin() fixes the frame and clears the context's
+ * own accumulation buffer; every rt_progress_step() renders the next `max_samples` samples of every pixel (blocking for that
+ * slice only - milliseconds) and writes the image of all samples so far to rgb8_out, so a caller polling once per UI frame shows
+ * a picture that sharpens until *finished is set.  Sample streams are keyed by the global sample index: the last image is the
+ * one rt_render() returns for the same parameters. */
+int rt_progress_begin(rt_context* ctx, const rt_render_params* params);
+int rt_progress_step(rt_context* ctx, uint32_t max_samples, uint8_t* rgb8_out /* width*height*3, row 0 on top */,
+                     uint32_t* samples_done /* of sample_end - sample_begin, may be NULL */, int* finished /* may be NULL */,
+                     rt_stats* stats /* of this step, may be NULL */);
+
 /* ---- multi-GPU: one context per GPU (one process or thread each), sums reduced onto one rank over RCCL / xGMI ----
  * The reference partitions image rows over worker threads (src/render.rs:218-224) and gathers pixels through an mpsc channel
  * (src/render.rs:185,192-201).  Here every rank renders its slice of the SAMPLE range of the whole frame with rt_render_accum

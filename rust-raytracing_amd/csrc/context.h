@@ -76,6 +76,10 @@ struct rt_context {
   size_t accum_bytes = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   unsigned long long* h_rays = nullptr;  // one page-locked host word: where the allocation-free entry point receives its ray count
+  // progressive rendering (rt_progress_*): the frame in progress and the next sample to render
+  rt_render_params progress{};
+  uint32_t progress_next = 0;
+  bool progress_active = false;
   // multi-GPU (comm.hip): RCCL communicator this context's GPU belongs to, its rank, and the packed W*H*3 staging buffer
   void* comm = nullptr;
   int comm_rank = 0, comm_size = 1;

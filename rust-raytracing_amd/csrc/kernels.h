@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : (sizeof(R
 #endif
 constexpr uint32_t kStepThreads = RT_STEP_THREADS;
 #ifndef RT_RESTART_LANES
-#define RT_RESTART_LANES 24
+#define RT_RESTART_LANES 32
 #define RT_BOX_STEPS 4
 #define RT_TURNS 4
 #endif

@@ -489,6 +489,48 @@ int rt_render(rt_context* c, const rt_render_params* p, uint8_t* rgb8_out, doubl
   return rc;
 }
 
+int rt_progress_begin(rt_context* c, const rt_render_params* p) {
+  int rc = check_render_params(c, p);
+  if (rc) return rc;
+  if (p->sample_end == p->sample_begin) return fail(RT_E_INVALID, "cannot resolve an image of zero samples");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t bytes = (size_t)p->width * p->height * 4 * (p->precision == RT_PRECISION_F64 ? sizeof(double) : sizeof(float));
+  rt_render_params none = *p;
+  none.sample_end = none.sample_begin;  // renders nothing: allocates (if need be) and clears the context's own buffer
+  rc = rt_render_accum(c, &none, nullptr, nullptr);
+  if (rc) return rc;
+  if (!c->accum || c->accum_bytes < bytes) return fail(RT_E_HIP, "rt_progress_begin: no accumulation buffer");
+  c->progress = *p;
+  c->progress_next = p->sample_begin;
+  c->progress_active = true;
+  return RT_OK;
+}
+
+int rt_progress_step(rt_context* c, uint32_t max_samples, uint8_t* rgb8_out, uint32_t* samples_done, int* finished, rt_stats* stats) {
+  if (!c || !rgb8_out) return fail(RT_E_INVALID, "context or output is NULL");
+  if (!c->progress_active) return fail(RT_E_INVALID, "rt_progress_step before rt_progress_begin");
+  if (max_samples == 0) return fail(RT_E_INVALID, "max_samples is 0");
+  if (!c->has_scene) return fail(RT_E_NO_SCENE, "no scene uploaded");
+  const rt_render_params& f = c->progress;
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  if (c->progress_next < f.sample_end) {
+    rt_render_params slice = f;
+    slice.sample_begin = c->progress_next;
+    slice.sample_end = f.sample_end - c->progress_next > max_samples ? c->progress_next + max_samples : f.sample_end;
+    HIP_TRY(hipSetDevice(c->device));
+    // into the context's own buffer WITHOUT clearing it: hand its address over as a caller's buffer
+    int rc = rt_render_accum(c, &slice, c->accum, stats);
+    if (rc) return rc;
+    c->progress_next = slice.sample_end;
+  }
+  const uint32_t done = c->progress_next - f.sample_begin;
+  int rc = rt_resolve(c, nullptr, f.width, f.height, done, f.precision, rgb8_out);
+  if (rc) return rc;
+  if (samples_done) *samples_done = done;
+  if (finished) *finished = c->progress_next >= f.sample_end ? 1 : 0;
+  return RT_OK;
+}
+
 int rt_render_noalloc(rt_context* c, const rt_render_params* p, void* accum_dev, uint8_t* rgb8_out, rt_stats* stats) {
   int rc = check_render_params(c, p);
   if (rc) return rc;

@@ -29,7 +29,7 @@ SCENES = {
 
 # every symbol include/rtamd.h and include/rtamd_host.h declare
 ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_upload_scene", "rt_render_accum", "rt_resolve", "rt_read_accum", "rt_render", "rt_render_noalloc",
-               "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_reduce_accum",
+               "rt_progress_begin", "rt_progress_step", "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_reduce_accum",
                "rt_trace_batch", "rt_camera_rays", "rt_sample_radiance", "rt_sample_path", "rt_last_error", "rt_version"]
 HOST_ABI_SYMBOLS = ["rth_scene_create", "rth_scene_destroy", "rth_scene_desc", "rth_scene_config", "rth_scene_from_name",
                     "rth_scene_name", "rth_save_image", "rth_load_ppm", "rth_free", "rth_render_and_save", "rth_last_error"]
@@ -112,6 +112,8 @@ def load_libraries():
     L.rt_read_accum.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_int, vp]
     L.rt_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
     L.rt_render_noalloc.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
+    L.rt_progress_begin.argtypes = [vp, C.POINTER(RenderParams)]
+    L.rt_progress_step.argtypes = [vp, C.c_uint32, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(Stats)]
     L.rt_comm_unique_id.argtypes = [vp]
     L.rt_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     L.rt_comm_destroy.argtypes = [vp]
@@ -277,6 +279,19 @@ class Context:
         st = Stats()
         _check(self.L.rt_render_noalloc(self.h, C.byref(p), C.c_void_p(accum_dev_ptr), _p(rgb_out), C.byref(st)))
         return st.as_dict()
+
+    def progress_begin(self, s_begin=0, s_end=None, precision=F32, pipeline=PIPELINE_AUTO, seed=0, depth=None, width=0, height=0):
+        """rt_progress_begin: fixes the frame of a progressive render."""
+        p = self._params(width, height, s_begin, self.scene.spp if s_end is None else s_end, depth, precision, pipeline, 0, seed)
+        _check(self.L.rt_progress_begin(self.h, C.byref(p)))
+        self._progress_shape = (p.height, p.width, 3)
+
+    def progress_step(self, max_samples, out=None):
+        """rt_progress_step: renders the next slice; returns (rgb8 of all samples so far, samples done, finished, stats)."""
+        rgb = out if out is not None else np.zeros(self._progress_shape, dtype=np.uint8)
+        done, fin, st = C.c_uint32(), C.c_int(), Stats()
+        _check(self.L.rt_progress_step(self.h, max_samples, _p(rgb), C.byref(done), C.byref(fin), C.byref(st)))
+        return rgb, done.value, bool(fin.value), st.as_dict()
 
     def comm_init(self, comm_id, n_ranks, rank):
         """rt_comm_init: joins this context's GPU to the communicator identified by the 128 bytes of `comm_id`."""

@@ -300,3 +300,38 @@ def test_million_sphere_field(gpu, rtamd):
     assert abs(int(s32["rays"]) - int(s64["rays"])) <= 5e-3 * s64["rays"], (s32["rays"], s64["rays"])
     m32, m64 = np.clip(a32 / 4, 0, 1).reshape(-1, 3).mean(0), np.clip(a64 / 4, 0, 1).reshape(-1, 3).mean(0)
     assert (np.abs(m32 - m64) / m64).max() < 1e-2, (m32, m64)
+
+
+def test_progressive_render_ends_at_the_one_shot_image(gpu, rtamd):
+    """rt_progress_begin / rt_progress_step (the polling side of ThreadedRenderer, src/render.rs:69-108): the image refines slice
+    by slice and ends exactly where rt_render arrives in one go."""
+    hs = rtamd.Scene("cornell-box", width=96, aspect=1.0, spp=10)
+    gpu.upload(hs)
+    fresh = rtamd.Context(0)
+    fresh.upload(hs)
+    fresh._progress_shape = (96, 96, 3)
+    with pytest.raises(rtamd.RtError):
+        fresh.progress_step(1)  # before rt_progress_begin
+    fresh.close()
+    for prec in (rtamd.F64, rtamd.F32):
+        want_rgb, want, st = gpu.render(0, 10, precision=prec, seed=4)
+        gpu.progress_begin(0, 10, precision=prec, seed=4)
+        seen, rays, images = [], 0, []
+        for _ in range(10):
+            rgb, done, fin, s = gpu.progress_step(4)
+            seen.append(done)
+            rays += s["rays"]
+            images.append(rgb.copy())
+            if fin:
+                break
+        assert seen == [4, 8, 10] and rays == st["rays"]
+        got = gpu.read_accum(None, 96, 96, precision=prec)
+        tol = 1e-12 if prec == rtamd.F64 else 1e-4
+        assert np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max())
+        assert np.abs(images[-1].astype(int) - want_rgb.astype(int)).max() <= 1
+        # a further step renders nothing and returns the same picture
+        rgb, done, fin, s = gpu.progress_step(4)
+        assert done == 10 and fin and s["rays"] == 0 and np.array_equal(rgb, images[-1])
+        # earlier pictures are noisier estimates of the whole frame (lit pixels in every quarter of it), not parts of it
+        first = images[0].reshape(2, 48, 2, 48, 3).max(axis=(1, 3, 4))
+        assert (first > 0).all(), first
