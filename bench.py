@@ -119,6 +119,7 @@ def main():
                         mega_grid=args.mega_grid)
     t_scene = time.perf_counter() - t_scene
     W, H = scene.width, scene.height
+    n_objects = int(scene.desc.n_objects)
     ctx = rtamd.Context(local_rank)
     t_upload = time.perf_counter()
     ctx.upload(scene)
@@ -222,7 +223,7 @@ def main():
         # per-lane walks of trees that do not fit on chip: what a closest-hit query costs on the tree THIS precision walks (the f64
         # kernels walk the reference's tree, the f32 kernels the library's own), measured on the device over the rays of 8192 paths
         walk = None
-        if rank == 0 and stats and stats[-1]["scene_in_lds"] in (4, 6, 8):
+        if rank == 0 and stats and stats[-1]["scene_in_lds"] in (4, 6, 8) and n_objects >= 100_000:
             walk = ctx.walk_cost(prec, n_paths=8192, seed=1)
         return {"name": name, "walk": walk, "elapsed": elapsed_max, "rays": rays, "rays_all": rays_all, "kernel_ms": kernel_ms, "launches": launches,
                 "stats": stats, "rgb": None if rgb is None else rgb.copy(), "accum": accum, "split": split, "per_rank": per_rank}

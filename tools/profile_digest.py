@@ -18,6 +18,7 @@ RENDER_KERNELS = ("k_paths_persistent", "k_paths_stepwise", "k_bounce_fused", "k
 def digest(tag, prec, scene, spp, src, dst):
     tot = {}
     launches = {}
+    owner = {}  # counter -> the pass it is taken from (a counter collected in two passes must not be added up twice)
     for d in sorted(glob.glob(os.path.join(src, "pmc_%s_*" % prec))):
         if not os.path.isdir(d):
             continue
@@ -30,7 +31,8 @@ def digest(tag, prec, scene, spp, src, dst):
                     if kern is None:
                         continue
                     t = tot.setdefault(kern, {})
-                    t[r["Counter_Name"]] = t.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                    if owner.setdefault((kern, r["Counter_Name"]), d) == d:
+                        t[r["Counter_Name"]] = t.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
                     if (r["Dispatch_Id"], kern) not in seen and os.path.basename(d).endswith("_fetch"):
                         seen.add((r["Dispatch_Id"], kern))
                         launches[kern] = launches.get(kern, 0) + 1
