@@ -32,6 +32,8 @@ constexpr uint32_t kBlockThreads = 256;
 #ifndef RT_STEPWISE_NESTED
 #define RT_STEPWISE_NESTED 0
 #endif
+// The chunked variant of the persistent kernel exists for the small sphere scenes only (see render_accum_impl for when it runs).
+template <class C> constexpr bool chunked_variant() { return C::walk == WALK_UNIFORM && C::has(F_SPHERE); }
 template <class C> constexpr bool use_stepwise() { return C::walk != WALK_UNIFORM && (RT_STEPWISE_NESTED || !C::has(F_NESTED)); }
 
 template <class R, class C> KernelTable<R> make_table() {
@@ -45,6 +47,13 @@ template <class R, class C> KernelTable<R> make_table() {
                           unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
     const bool fixed = fp.path_grab == kPathGrab;
     if constexpr (!use_stepwise<C>()) {
+      if constexpr (chunked_variant<C>()) {
+        if (fp.chunk > 1u) {
+          if (fixed) hipLaunchKernelGGL((k_paths_persistent<R, C, true, true>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
+          else hipLaunchKernelGGL((k_paths_persistent<R, C, false, true>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
+          return;
+        }
+      }
       if (fixed) hipLaunchKernelGGL((k_paths_persistent<R, C, true>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
       else hipLaunchKernelGGL((k_paths_persistent<R, C, false>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
     }

@@ -69,6 +69,10 @@ RT_DEV uint32_t compact_slot(bool keep, uint32_t* counter) {
 }
 
 template <class R> RT_DEV void add_radiance(R* accum, uint32_t pixel, V3<R> c) {
+#ifdef RT_EXP_NOATOMIC  // diagnostic build only: what the radiance atomics cost (the image stays black)
+  if (c.x == (R)-1.2345) accum[pixel] = c.y;
+  return;
+#endif
   if (c.x != (R)0 || c.y != (R)0 || c.z != (R)0) {
     R* px = accum + (size_t)pixel * 4u;
     atomicAdd(px + 0, c.x);
@@ -118,6 +122,11 @@ struct FrameParams {
   // Paths a wave of the path kernels takes from the global cursor at a time: kPathGrab on large frames, fewer when the frame has
   // only a few grabs per wave to hand out (the last grabs decide how evenly the frame ends).
   uint32_t path_grab;
+  // k_paths_persistent: a lane takes `chunk` consecutive samples of ONE pixel, sums their radiance in registers and adds the
+  // sum to the pixel's slot once (the unit the feeder hands out is then a chunk: unit u = chunk index u / n_pixels of pixel
+  // u % n_pixels).  `n_samples` = samples of this launch.  Frames whose paths are short and all bright (a textured globe in
+  // front of a sky) otherwise spend two thirds of their time in the radiance atomics.
+  uint32_t chunk, n_samples;
 };
 
 struct Segment {
@@ -301,8 +310,13 @@ template <class R> struct PathFeeder {
 #ifndef RT_SMALL_WAVES_F64
 #define RT_SMALL_WAVES_F64 1
 #endif
-template <class R, class C, bool FIXED_GRAB>
-__global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : (sizeof(R) == 8 ? RT_SMALL_WAVES_F64 : 1)) void k_paths_persistent(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
+#ifndef RT_NOISE_WAVES
+#define RT_NOISE_WAVES 4  // single precision only: the Perlin code wants 136 registers; 128 (four waves per SIMD) is worth 7 % on the noise scenes
+#endif
+// CHUNKED: see FrameParams::chunk.  Carrying a chunk's sum costs three registers and a dozen instructions a turn (5-15 % on
+// frames that do not need it), so the launcher picks this variant only for frames made of short, cheap, bright paths.
+template <class R, class C, bool FIXED_GRAB, bool CHUNKED = false>
+__global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : (C::has(F_NOISE) && sizeof(R) == 4 ? RT_NOISE_WAVES : (sizeof(R) == 8 ? RT_SMALL_WAVES_F64 : 1))) void k_paths_persistent(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
                                                           unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
   extern __shared__ __align__(16) uint8_t lds[];
   const SceneView<R, C> sv = make_view<R, C>(sc, lds);
@@ -315,29 +329,65 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : (sizeof(R
   unsigned long long n_rays = 0;
   PathState<R> st;
   Rec<R> rec;
+  V3<R> sum((R)0, (R)0, (R)0);  // radiance of the samples of the lane's chunk so far
+  uint32_t more = 0;            // samples of the chunk still to start after the current one
   RT_STAMP_INIT();
-  // One turn: paths that end at their last hit are closed, their lanes take new paths, then ONE evaluation of Philox serves
-  // the scatter draw of the continuing lanes and the pixel jitter of the new ones, and all lanes trace their next ray.
+  // One turn: paths that end at their last hit are closed - their lanes go on with the next sample of their chunk or, the chunk
+  // done, add its sum to the pixel and take a new chunk - then ONE evaluation of Philox serves the scatter draw of the continuing
+  // lanes and the pixel jitter of the starting ones, and all lanes trace their next ray.
   for (;;) {
     RT_STAMP(6);
     bool to_scatter = false;
+    bool absorbed = false;
     if (active) {
+      bool ended = true;
+      V3<R> term((R)0, (R)0, (R)0);
       if (!hit) {
-        add_radiance(accum, st.pixel, st.thr * background_color<R, C>(sc.background, st.ray.d));
-        active = false;
+        term = st.thr * background_color<R, C>(sc.background, st.ray.d);
       } else if (sv.materials[rec.mat].tag == MAT_LIGHT) {  // emits, never scatters (src/material.rs:148-167)
         V3<R> emitted, attenuation;
         Ray<R> scattered;
         shade_hit<R, C>(sv, st.ray, rec, Stream(fp.seed, st.pixel, st.sample, bounce, STAGE_SCATTER), emitted, attenuation, scattered);
-        add_radiance(accum, st.pixel, st.thr * emitted);
-        active = false;
+        term = st.thr * emitted;
       } else if (bounce + 1u >= fp.max_depth) {  // ray_color(depth == 0) contributes nothing (src/render.rs:151-153)
-        active = false;
       } else {
         to_scatter = true;
+        ended = false;
+      }
+      if constexpr (CHUNKED) {
+        if (ended) {
+          sum = sum + term;
+          if (more != 0u) {  // the next sample of the same pixel, in place
+            more -= 1u;
+            st.sample += 1u;
+            st.thr = V3<R>((R)1, (R)1, (R)1);
+            st.org = Origin();
+            bounce = 0;
+          } else {
+            add_radiance(accum, st.pixel, sum);
+            active = false;
+          }
+        }
+      } else {
+        if (ended) {
+          add_radiance(accum, st.pixel, term);
+          active = false;
+        }
       }
     }
-    feeder.template refill<false, FIXED_GRAB>(sc, fp, total_paths, path_cursor, st, bounce, active);
+    if constexpr (CHUNKED) {
+      const bool was_active = active;
+      feeder.template refill<false, FIXED_GRAB>(sc, fp, total_paths, path_cursor, st, bounce, active);
+      if (active && !was_active) {  // a new chunk: the feeder's "sample" is the chunk's index
+        const uint32_t first = (st.sample - fp.sample_base) * fp.chunk;
+        const uint32_t n = fp.n_samples - first < fp.chunk ? fp.n_samples - first : fp.chunk;
+        st.sample = fp.sample_base + first;
+        more = n - 1u;
+        sum = V3<R>((R)0, (R)0, (R)0);
+      }
+    } else {
+      feeder.template refill<false, FIXED_GRAB>(sc, fp, total_paths, path_cursor, st, bounce, active);
+    }
     RT_STAMP(0);
     if (__ballot(active) == 0ull) break;
     const PrimedStream rng(Stream(fp.seed, st.pixel, st.sample, bounce, to_scatter ? STAGE_SCATTER : STAGE_CAMERA), to_scatter ? resume : 0u, kBlocksPerTurn);
@@ -351,13 +401,17 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : (sizeof(R
         st.thr = st.thr * attenuation;
         st.ray = scattered;
         st.org = Origin(rec.leaf, rec.side);
-        active = alive;
+        if constexpr (CHUNKED) absorbed = !alive;
+        else active = alive;
       }
     } else if (active) {
       st.ray = primary_ray<R, C::relaxed()>(sc.camera, fp.width, fp.height, st.pixel, rng);
     }
     RT_STAMP(2);
-    const bool go = active && resume == 0u;
+    // an absorbed path (a metal's scattered ray below the surface, src/material.rs:88-90) ends here: it sits out this trace as a
+    // miss that adds nothing, and the next turn closes it like any other ended path
+    const bool go = active && resume == 0u && !absorbed;
+    if (absorbed) { hit = false; st.thr = V3<R>((R)0, (R)0, (R)0); }
     n_rays += (unsigned long long)__popcll(__ballot(go));
     if (go) {
       hit = false;

@@ -251,7 +251,16 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
     fp.width = p.width; fp.height = p.height; fp.n_pixels = (uint32_t)n_pixels;
     fp.sample_base = p.sample_begin; fp.n_paths = 0; fp.max_depth = p.max_depth; fp.seed = p.seed;
     fp.n_seg = kSegments; fp.seg_cap = 0;
-    const unsigned long long total_paths = (unsigned long long)n_pixels * n_samples;
+    // Chunks of up to 16 samples of one pixel per lane, summed in registers (FrameParams::chunk): for the small sphere scenes
+    // under a bright sky without procedural textures - a globe or two, every path a bounce or two long and every one of them
+    // bright - where one radiance atomic per path is two thirds of the frame time.  Everywhere else a unit is a single path.
+    const bool bright_sky = im.dev.background.c0.x + im.dev.background.c0.y + im.dev.background.c0.z > (R)0;
+    const bool cheap_paths = im.preset == PRESET_SPHERES && im.dev.lay.n_perlins == 0 && bright_sky;
+    uint32_t chunk = cheap_paths ? std::min<uint32_t>(16u, std::max<uint32_t>(1u, n_samples)) : 1u;
+    if (const char* e = getenv("RTAMD_CHUNK")) chunk = im.preset == PRESET_SPHERES ? (uint32_t)std::max(1, atoi(e)) : 1u;  // measurement switch
+    fp.chunk = chunk;
+    fp.n_samples = n_samples;
+    const unsigned long long total_paths = (unsigned long long)n_pixels * ((n_samples + chunk - 1) / chunk);  // units the path cursor counts
 #ifdef RT_STAMPS
     if (counters_override) return fail(RT_E_UNSUPPORTED, "the diagnostic build has no allocation-free entry point");
     HIP_TRY(hipMemsetAsync(c->d_ray_count, 0, sizeof(unsigned long long) * kRayCountWords, c->stream));
