@@ -155,8 +155,8 @@ def main():
     def run_leg(name, steps, warmup):
         """W warm-up frames, then `steps` timed frames of the whole job in arithmetic `name`; returns the figures of the leg
         (on every rank; `accum` holds the reduced sums on rank 0)."""
-        prec = rtamd.F64 if name == "f64" else rtamd.F32
-        accum = torch.zeros(H * W * 4, dtype=torch.float64 if name == "f64" else torch.float32, device=dev)
+        prec = {"f64": rtamd.F64, "f64_own_tree": rtamd.F64_OWN_TREE, "f32": rtamd.F32}[name]
+        accum = torch.zeros(H * W * 4, dtype=torch.float32 if name == "f32" else torch.float64, device=dev)
         # channel 3 of a pixel's slot is unused: the reduce carries the three colour sums only
         packed = torch.zeros(H * W * 3, dtype=accum.dtype, device=dev) if dist is not None else None
         split = {"render_s": 0.0, "reduce_s": 0.0, "resolve_s": 0.0}
@@ -229,7 +229,7 @@ def main():
                 "stats": stats, "rgb": None if rgb is None else rgb.copy(), "accum": accum, "split": split, "per_rank": per_rank}
 
     def roofline_of(leg, fpr):
-        name = leg["name"]
+        name = "f32" if leg["name"] == "f32" else "f64"  # the arithmetic; leg["name"] also tells the tree
         if fpr is None or leg["kernel_ms"] <= 0:
             return None
         stats = leg["stats"]
@@ -285,6 +285,10 @@ def main():
     head_name = "f32" if args.precision == "f32" else "f64"
     head = run_leg(head_name, args.steps, args.warmup)
     side = run_leg("f32", args.steps, args.warmup) if args.precision == "both" else None
+    # scenes that take a per-lane preset have a second double-precision image over the library's own tree (RT_F64_OWN_TREE)
+    own = None
+    if args.precision == "both" and head["stats"] and head["stats"][-1]["scene_in_lds"] >= 3:
+        own = run_leg("f64_own_tree", args.steps, args.warmup)
 
     if rank == 0:
         headline = (args.scene, args.width, args.spp) == ("cornell-box", 1920, 1024)
@@ -361,6 +365,23 @@ def main():
                             "rounding plus the paths that part where single precision resolves an edge differently",
                 },
             }
+        if own is not None:
+            b64 = (own["accum"].view(-1, 4)[:, :3] / args.spp).clamp(0.0, 1.0)
+            a64 = (head["accum"].view(-1, 4)[:, :3] / args.spp).clamp(0.0, 1.0)
+            d8 = np.abs(head["rgb"].astype(np.int16) - own["rgb"].astype(np.int16))
+            out["f64_own_tree"] = {
+                "value": own["rays_all"] / own["elapsed"] / 1e6, "unit": "Mrays/s", "dtype": "f64",
+                "ms_per_step": 1e3 * own["elapsed"] / max(1, args.steps), "steps": args.steps, "warmup": args.warmup,
+                "roofline": roofline_of(own, fpr),
+                "image_error_vs_f64": {
+                    "mean_error_rel": [float(x) for x in ((b64.mean(0) - a64.mean(0)).abs() / a64.mean(0).clamp_min(1e-12))],
+                    "rmse": [float(x) for x in ((b64 - a64) ** 2).mean(0).sqrt()],
+                    "rgb8_max_abs_diff": int(d8.max()), "rgb8_frac_bytes_differing": float((d8 > 0).mean()),
+                    "rays_rel_diff": abs(own["rays_all"] - head["rays_all"]) / head["rays_all"]},
+                "note": "double arithmetic on the tree the library builds for itself (RT_PRECISION_F64 | RT_F64_OWN_TREE) instead of the "
+                        "caller's: same closest hits, the reference's last-tested-wins rule for exactly coincident surfaces given up",
+            }
+        if side is not None:
             if world > 1:
                 out["f32"]["per_rank_ms"] = {"columns": ["kernel", "render_call", "reduce", "resolve_and_copy"], "ranks": side["per_rank"]}
         print(json.dumps(out), flush=True)

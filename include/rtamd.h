@@ -39,6 +39,12 @@ extern "C" {
 /* Arithmetic type of the device kernels.  The reference computes in f64. */
 #define RT_PRECISION_F32 0
 #define RT_PRECISION_F64 1
+/* RT_PRECISION_F64 | RT_F64_OWN_TREE: double-precision arithmetic on the tree the library builds for itself (the one the F32
+ * kernels walk) instead of the tree the caller uploaded.  The closest hit does not depend on the tree, so images agree to
+ * rounding; what is given up is the reference's rule for exactly coincident surfaces (the last one its walk tests wins), which
+ * only the caller's tree can reproduce.  Several times faster on large scenes (the reference's random-axis tree tests 105 boxes
+ * per ray on a million spheres, the library's 47).  Scenes that take a small-scene preset have no such tree: the flag is ignored. */
+#define RT_F64_OWN_TREE 0x400
 
 /* Pipeline.  FUSED = per-bounce ray queues, one trace+shade kernel per bounce;
  * SORTED = per-bounce ray queues, trace kernel writing hit records binned by

@@ -145,6 +145,7 @@ int rt_comm_destroy(rt_context* c) {
 
 int rt_reduce_accum(rt_context* c, void* accum_dev, uint32_t width, uint32_t height, int precision, int root) {
   if (!c) return fail(RT_E_INVALID, "context is NULL");
+  precision &= ~RT_F64_OWN_TREE;
   if (precision != RT_PRECISION_F32 && precision != RT_PRECISION_F64) return fail(RT_E_INVALID, "unknown precision");
   if (!c->comm) return fail(RT_E_INVALID, "rt_reduce_accum before rt_comm_init");
   if (root < 0 || root >= c->comm_size) return fail(RT_E_INVALID, "root out of range");

@@ -65,6 +65,8 @@ struct rt_context {
   bool has_scene = false;
   rti::SceneImage<float> sf;
   rti::SceneImage<double> sd;
+  rti::SceneImage<double> sd_own;  // double-precision image over the library's own tree (RT_F64_OWN_TREE); empty for small-scene presets
+  bool own64 = false;              // the call in progress asked for it
   rtd::DImage* d_images = nullptr;
   std::vector<uint8_t*> d_image_bytes;
   // render workspace
@@ -92,7 +94,12 @@ namespace rti {
 
 template <class R> SceneImage<R>& image_of(rt_context* c);
 template <> inline SceneImage<float>& image_of<float>(rt_context* c) { return c->sf; }
-template <> inline SceneImage<double>& image_of<double>(rt_context* c) { return c->sd; }
+template <> inline SceneImage<double>& image_of<double>(rt_context* c) { return (c->own64 && c->sd_own.d_blob) ? c->sd_own : c->sd; }
+// Strips RT_F64_OWN_TREE from a precision argument and notes on the context whether the call asked for the library's own tree.
+inline int select_tree(rt_context* c, int precision) {
+  if (c) c->own64 = (precision & RT_F64_OWN_TREE) != 0 && (precision & ~RT_F64_OWN_TREE) == RT_PRECISION_F64;
+  return precision & ~RT_F64_OWN_TREE;
+}
 
 // Workgroups per CU that stay resident for a kernel: the runtime's estimate, at most 8 (two waves per SIMD and workgroup), and one
 // less than the estimate when that leaves a margin (the estimate has been seen one too high for kernels near an SGPR allocation

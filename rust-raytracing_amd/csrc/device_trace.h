@@ -283,6 +283,10 @@ RT_DEV bool boundary_hit(const SceneView<R, C>& sv, const DObject<R>& ob, int ob
       rec.p = rec.p + V3<R>(ob.offset[0], ob.offset[1], ob.offset[2]);
       rec.set_face_normal(moved.d, rec.n);
     }
+    if (ob.flags & OBJ_FRONT_CHAIN) {  // a re-centred sphere: front_face as RotateY's mixed-frame call would have left it (src/hittable.rs:236-239)
+      const R dlx = ob.cos_theta * ray.d.x - ob.sin_theta * ray.d.z, dlz = ob.sin_theta * ray.d.x + ob.cos_theta * ray.d.z;
+      rec.front = (dlx * rec.n.x + ray.d.y * rec.n.y + dlz * rec.n.z) < (R)0;
+    }
   }
   return true;
 }

@@ -138,6 +138,9 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
     for (int k = 0; k < 3; ++k) { L[i].bmin[k] = round_down<R>(links[i].bmin[k]); L[i].bmax[k] = round_up<R>(links[i].bmax[k]); }
     L[i].hit = links[i].hit;
     L[i].miss = links[i].miss;
+    // the double-precision walk looks at an object's flags only when its leaf is not marked simple; a re-centred sphere's
+    // front_face rule lives in those flags (the single-precision walk reads them when it writes the record)
+    if (!single && (links[i].hit & LEAF_FLAG) && (s.objects[links[i].hit & LEAF_INDEX_MASK].flags & OBJ_FRONT_CHAIN)) L[i].hit &= ~LEAF_SIMPLE;
   }
   auto* S = reinterpret_cast<DShape<R>*>(blob.data() + lay.shapes_off);
   auto* O = reinterpret_cast<DObject<R>*>(blob.data() + lay.objects_off);

@@ -50,6 +50,7 @@ template <class R> void free_image(SceneImage<R>& im) {
 void free_scene(rt_context* c) {
   free_image(c->sf);
   free_image(c->sd);
+  free_image(c->sd_own);
   if (c->d_images) (void)hipFree(c->d_images);
   c->d_images = nullptr;
   for (uint8_t* p : c->d_image_bytes) (void)hipFree(p);
@@ -176,7 +177,7 @@ int check_render_params(const rt_context* c, const rt_render_params* p) {
   if ((uint64_t)p->width * p->height > 0x7FFFFFFFull) return fail(RT_E_INVALID, "image too large");
   if (p->sample_end < p->sample_begin) return fail(RT_E_INVALID, "sample_end < sample_begin");
   if (p->max_depth > kMaxDepth) return fail(RT_E_INVALID, "max_depth exceeds 4096");
-  if (p->precision != RT_PRECISION_F32 && p->precision != RT_PRECISION_F64) return fail(RT_E_INVALID, "unknown precision");
+  if ((p->precision & ~RT_F64_OWN_TREE) != RT_PRECISION_F32 && (p->precision & ~RT_F64_OWN_TREE) != RT_PRECISION_F64) return fail(RT_E_INVALID, "unknown precision");
   if (p->pipeline < RT_PIPELINE_AUTO || p->pipeline > RT_PIPELINE_PERSISTENT) return fail(RT_E_INVALID, "unknown pipeline");
   return RT_OK;
 }
@@ -420,6 +421,9 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   rc = own_tree ? build_image<float>(c, scene32, fast_links, fast_root, fast_sub_root, preset32, c->sf)
                 : build_image<float>(c, *s, links, root, sub_root, preset, c->sf);
   if (rc == RT_OK) rc = build_image<double>(c, *s, links, root, sub_root, preset, c->sd);
+  // RT_F64_OWN_TREE: the library's tree once more, in double (the presets without nested-walk code exist in single only)
+  if (rc == RT_OK && own_tree && !std::getenv("RTAMD_NO_F64_OWN_TREE"))
+    rc = build_image<double>(c, scene32, fast_links, fast_root, fast_sub_root, preset32 == PRESET_FLATALL_LDS ? PRESET_ALL_LDS : preset32, c->sd_own);
   if (rc != RT_OK) { free_scene(c); return rc; }
   c->has_scene = true;
   return RT_OK;
@@ -430,12 +434,15 @@ int rt_render_accum(rt_context* c, const rt_render_params* p, void* accum_dev, r
   if (rc) return rc;
   HIP_TRY(hipSetDevice(c->device));
   if (stats) std::memset(stats, 0, sizeof(*stats));
-  if (p->precision == RT_PRECISION_F64) return render_accum_impl<double>(c, *p, accum_dev, stats);
-  return render_accum_impl<float>(c, *p, accum_dev, stats);
+  rt_render_params q = *p;
+  q.precision = select_tree(c, p->precision);
+  if (q.precision == RT_PRECISION_F64) return render_accum_impl<double>(c, q, accum_dev, stats);
+  return render_accum_impl<float>(c, q, accum_dev, stats);
 }
 
 int rt_resolve(rt_context* c, const void* accum_dev, uint32_t width, uint32_t height, uint32_t spp, int precision, uint8_t* rgb8_out) {
   if (!c || !rgb8_out) return fail(RT_E_INVALID, "context or output is NULL");
+  precision &= ~RT_F64_OWN_TREE;
   if (spp == 0) return fail(RT_E_INVALID, "samples_per_pixel is 0");
   if (precision != RT_PRECISION_F32 && precision != RT_PRECISION_F64) return fail(RT_E_INVALID, "unknown precision");
   HIP_TRY(hipSetDevice(c->device));
@@ -459,6 +466,7 @@ int rt_resolve(rt_context* c, const void* accum_dev, uint32_t width, uint32_t he
 
 int rt_read_accum(rt_context* c, const void* accum_dev, uint32_t width, uint32_t height, int precision, double* out) {
   if (!c || !out) return fail(RT_E_INVALID, "context or output is NULL");
+  precision &= ~RT_F64_OWN_TREE;
   if (precision != RT_PRECISION_F32 && precision != RT_PRECISION_F64) return fail(RT_E_INVALID, "unknown precision");
   HIP_TRY(hipSetDevice(c->device));
   const size_t n = (size_t)width * height;
@@ -494,7 +502,7 @@ int rt_progress_begin(rt_context* c, const rt_render_params* p) {
   if (rc) return rc;
   if (p->sample_end == p->sample_begin) return fail(RT_E_INVALID, "cannot resolve an image of zero samples");
   HIP_TRY(hipSetDevice(c->device));
-  const size_t bytes = (size_t)p->width * p->height * 4 * (p->precision == RT_PRECISION_F64 ? sizeof(double) : sizeof(float));
+  const size_t bytes = (size_t)p->width * p->height * 4 * ((p->precision & ~RT_F64_OWN_TREE) == RT_PRECISION_F64 ? sizeof(double) : sizeof(float));
   rt_render_params none = *p;
   none.sample_end = none.sample_begin;  // renders nothing: allocates (if need be) and clears the context's own buffer
   rc = rt_render_accum(c, &none, nullptr, nullptr);
@@ -545,13 +553,15 @@ int rt_render_noalloc(rt_context* c, const rt_render_params* p, void* accum_dev,
   auto t0 = std::chrono::steady_clock::now();
   HIP_TRY(hipSetDevice(c->device));
   if (stats) std::memset(stats, 0, sizeof(*stats));
-  const bool f64 = p->precision == RT_PRECISION_F64;
+  rt_render_params q = *p;
+  q.precision = select_tree(c, p->precision);
+  const bool f64 = q.precision == RT_PRECISION_F64;
   unsigned char* const scratch = static_cast<unsigned char*>(c->scratch);  // the device address, never the array's name
   unsigned long long* const counters = reinterpret_cast<unsigned long long*>(scratch);
   uint8_t* const d_rgb = scratch + RT_NOALLOC_COUNTER_BYTES;
   // the whole frame, as rt_render: sums start at zero; the counters are cleared inside (the array keeps the last call's contents)
   HIP_TRY(hipMemsetAsync(accum_dev, 0, n * 4 * (f64 ? sizeof(double) : sizeof(float)), c->stream));
-  rc = f64 ? render_accum_impl<double>(c, *p, accum_dev, stats, counters, c->h_rays) : render_accum_impl<float>(c, *p, accum_dev, stats, counters, c->h_rays);
+  rc = f64 ? render_accum_impl<double>(c, q, accum_dev, stats, counters, c->h_rays) : render_accum_impl<float>(c, q, accum_dev, stats, counters, c->h_rays);
   if (rc) return rc;
   const uint32_t spp = p->sample_end - p->sample_begin;
   rc = f64 ? resolve_impl<double>(c, accum_dev, n, spp, d_rgb) : resolve_impl<float>(c, accum_dev, n, spp, d_rgb);
@@ -570,6 +580,7 @@ int rt_trace_batch(rt_context* c, const rt_ray* rays, size_t n, rt_hit* hits, in
   if (n > 0x7FFFFFFFull) return fail(RT_E_INVALID, "batch too large");
   const int mode = (precision & RT_TRACE_VISITS) ? 2 : ((precision & RT_TRACE_AS_RENDERED) ? 1 : 0);
   precision &= ~(RT_TRACE_AS_RENDERED | RT_TRACE_VISITS);
+  precision = select_tree(c, precision);
   if (precision != RT_PRECISION_F32 && precision != RT_PRECISION_F64) return fail(RT_E_INVALID, "unknown precision");
   HIP_TRY(hipSetDevice(c->device));
   return precision == RT_PRECISION_F64 ? trace_batch_impl<double>(c, rays, n, hits, seed, mode)
@@ -580,6 +591,7 @@ int rt_camera_rays(rt_context* c, uint32_t width, uint32_t height, const uint32_
                    int precision, rt_ray* out) {
   if (!c) return fail(RT_E_INVALID, "context is NULL");
   if (!c->has_scene) return fail(RT_E_NO_SCENE, "no scene uploaded");
+  precision = select_tree(c, precision);
   if (n == 0) return RT_OK;
   if (!pixel || !sample || !out) return fail(RT_E_INVALID, "NULL argument");
   if (width < 2 || height < 2) return fail(RT_E_INVALID, "width and height must be at least 2");
@@ -594,6 +606,7 @@ int rt_sample_radiance(rt_context* c, uint32_t width, uint32_t height, uint32_t 
                        uint64_t seed, int precision, double* out) {
   if (!c) return fail(RT_E_INVALID, "context is NULL");
   if (!c->has_scene) return fail(RT_E_NO_SCENE, "no scene uploaded");
+  precision = select_tree(c, precision);
   if (n == 0) return RT_OK;
   if (!pixel || !sample || !out) return fail(RT_E_INVALID, "NULL argument");
   if (width < 2 || height < 2) return fail(RT_E_INVALID, "width and height must be at least 2");
@@ -609,6 +622,7 @@ int rt_sample_path(rt_context* c, uint32_t width, uint32_t height, uint32_t max_
                    uint64_t seed, int precision, uint32_t max_vertices, double* out) {
   if (!c) return fail(RT_E_INVALID, "context is NULL");
   if (!c->has_scene) return fail(RT_E_NO_SCENE, "no scene uploaded");
+  precision = select_tree(c, precision);
   if (n == 0) return RT_OK;
   if (!pixel || !sample || !out || max_vertices == 0) return fail(RT_E_INVALID, "NULL argument or max_vertices == 0");
   if (width < 2 || height < 2) return fail(RT_E_INVALID, "width and height must be at least 2");

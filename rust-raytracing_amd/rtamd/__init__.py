@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(BUILD_DIR, "librtamd.so")
 HOST_LIB_PATH = os.path.join(BUILD_DIR, "librtamd_host.so")
 
 F32, F64 = 0, 1
+F64_OWN_TREE = F64 | 0x400  # double arithmetic on the tree the library builds for itself (RT_F64_OWN_TREE)
 TRACE_AS_RENDERED = 0x100  # rt_trace_batch: records built by the render kernels' own configuration
 TRACE_VISITS = 0x200       # ... and u, v = box entries / leaves tested by the walk
 PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_SORTED, PIPELINE_PERSISTENT = 0, 1, 2, 3

@@ -261,6 +261,48 @@ def test_f32_tree_variants_agree(gpu, rtamd, oracle, earth_rgb, name, switch, mo
 
 
 
+@pytest.mark.parametrize("name,mega_grid", [("random", 0), ("final-scene", 0), ("mega-spheres", 40), ("cornell-box", 0)])
+def test_f64_on_the_librarys_own_tree(gpu, rtamd, oracle, earth_rgb, name, mega_grid):
+    """RT_F64_OWN_TREE: double arithmetic on the tree the library builds for itself.  Checked against the ORACLE like the default
+    double path: identical ids on every ray except exactly coincident surfaces (final-scene's ground boxes share side faces; the
+    reference reports the last one its walk tests, which only its own tree can reproduce) and the same distance bound.  A scene of
+    a small-scene preset has no second tree: the flag is ignored and the hits are bit-identical to the default path's."""
+    kw = dict(mega_grid=mega_grid, width=160, spp=4) if mega_grid else {}
+    hs, os_ = make_pair(rtamd, oracle, name, earth=earth_rgb, **kw)
+    gpu.upload(hs)
+    rng = np.random.default_rng(4242)
+    lo, hi = SCENE_BOXES.get(name, ((-40, 0.05, -40), (40, 3, 40)))  # mega-spheres at grid 40
+    rays = random_rays(rng, 200_000, lo, hi)
+    oh = os_.first_hit(rays, seed=99, precision=1)
+    a = gpu.trace_batch(rays, precision=rtamd.F64, seed=99)
+    b = gpu.trace_batch(rays, precision=rtamd.F64_OWN_TREE, seed=99)
+    if name == "cornell-box":
+        assert a.tobytes() == b.tobytes()
+        return
+    assert (oh["hit"] == 1).mean() > 0.05
+    same = np.ones(rays.size, dtype=bool)
+    for f in ID_FIELDS:
+        same &= b[f] == oh[f]
+    both = (b["hit"] == 1) & (oh["hit"] == 1)
+    tie = np.zeros(rays.size, dtype=bool)
+    tie[both] = dist_err(rays, b, oh, both) <= 1e-12  # the two candidates are at the same distance as far as doubles can tell
+    print("\n%s: %d of %d rays differ in ids from the oracle on the library's tree, all of them ties" % (name, int((~same).sum()), rays.size))
+    assert (same | tie).all(), (name, int((~(same | tie)).sum()), b[~(same | tie)][:1], oh[~(same | tie)][:1])
+    assert (~same).mean() < 1e-3
+    ok = same & (oh["hit"] == 1)
+    assert dist_err(rays, b, oh, ok).max() < 1e-11
+    scale = np.maximum(np.abs(oh["p"][ok]).max(axis=1), 1.0)
+    assert (np.abs(b["p"][ok] - oh["p"][ok]).max(axis=1) / scale).max() < 1e-11
+    assert np.abs(b["n"][ok] - oh["n"][ok]).max() < 1e-9
+    # and the walk is the cheaper one (final-scene: the counter does not see inside the nested tree the library dissolved)
+    if name == "final-scene":
+        return
+    va = gpu.trace_batch(rays[:20000], precision=rtamd.F64, seed=99, visits=True)
+    vb = gpu.trace_batch(rays[:20000], precision=rtamd.F64_OWN_TREE, seed=99, visits=True)
+    print("%s: box tests per ray %.1f on the reference's tree, %.1f on the library's" % (name, va["u"].mean(), vb["u"].mean()))
+    assert vb["u"].mean() < va["u"].mean()
+
+
 def test_medium_in_a_one_object_node(gpu, rtamd, oracle, earth_rgb):
     """With axis seed 13 the reference's tree of final-scene puts the fog-filled glass ball (object 6 of the world list, a
     ConstantMedium) alone into a one-object node, which holds it twice (src/bvh.rs:38) and calls it twice (src/bvh.rs:114-116).

@@ -302,6 +302,25 @@ def test_million_sphere_field(gpu, rtamd):
     assert (np.abs(m32 - m64) / m64).max() < 1e-2, (m32, m64)
 
 
+@pytest.mark.parametrize("name", ["random", "final-scene"])
+def test_f64_own_tree_renders_the_same_frame(gpu, rtamd, oracle, earth_rgb, name):
+    """RT_F64_OWN_TREE renders what the default double path renders: the same ray count to 0.1 %, the same 8-bit pixels on all
+    but a few (a path that meets an exact tie, or a re-centred sphere whose hit point differs in the last bit, parts ways inside
+    the chaotic clusters), and radiance sums that agree to Monte-Carlo noise of those few pixels."""
+    w, spp = SMALL[name]
+    hs, _ = make_pair(rtamd, oracle, name, earth=earth_rgb, width=w, spp=spp)
+    gpu.upload(hs)
+    rgb_a, a, sa = gpu.render(0, spp, precision=rtamd.F64, seed=21)
+    rgb_b, b, sb = gpu.render(0, spp, precision=rtamd.F64_OWN_TREE, seed=21)
+    assert sa["camera_rays"] == sb["camera_rays"]
+    assert abs(int(sa["rays"]) - int(sb["rays"])) <= 1e-3 * sa["rays"], (sa["rays"], sb["rays"])
+    differ = (rgb_a != rgb_b).reshape(-1, 3).any(axis=1).mean()
+    print("\n%s: %.3f%% of the pixels differ between the two trees in f64" % (name, 100 * differ))
+    assert differ < 0.02, differ
+    ma, mb = np.clip(a / spp, 0, 1).reshape(-1, 3).mean(0), np.clip(b / spp, 0, 1).reshape(-1, 3).mean(0)
+    assert (np.abs(ma - mb) / ma).max() < 2e-3, (ma, mb)
+
+
 def test_progressive_render_ends_at_the_one_shot_image(gpu, rtamd):
     """rt_progress_begin / rt_progress_step (the polling side of ThreadedRenderer, src/render.rs:69-108): the image refines slice
     by slice and ends exactly where rt_render arrives in one go."""
