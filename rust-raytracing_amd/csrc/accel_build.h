@@ -12,11 +12,14 @@
 //   * the split is chosen by the surface-area heuristic over 16 bins per axis.
 #pragma once
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
-#include <map>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "context.h"
@@ -86,6 +89,7 @@ class FastTreeBuilder {
   struct Node {
     Box3d box;
     int left = -1, right = -1, obj = -1;
+    int n_links = 0;  // entries the subtree takes in the threaded list
   };
 
   // Objects of one reference tree, each once, ordered by the LAST time the reference's walk visits them.
@@ -109,29 +113,47 @@ class FastTreeBuilder {
     return out;
   }
 
-  // Everything that decides what a ray sees of an object, by value.
-  std::vector<double> signature(int o) const {
+  // Everything that decides what a ray sees of an object, by value (compared bit for bit).
+  struct Signature {
+    double v[28];
+    bool operator==(const Signature& o) const { return std::memcmp(v, o.v, sizeof(v)) == 0; }
+  };
+  struct SignatureHash {
+    size_t operator()(const Signature& g) const {
+      uint64_t h = 0x9E3779B97F4A7C15ull;
+      for (double d : g.v) {
+        uint64_t b;
+        std::memcpy(&b, &d, 8);
+        h = (h ^ b) * 0xFF51AFD7ED558CCDull;
+        h ^= h >> 32;
+      }
+      return (size_t)h;
+    }
+  };
+  Signature signature(int o) const {
     const rt_object& ob = s_.objects[o];
-    std::vector<double> v;
-    v.push_back((double)ob.flags);
-    for (int k = 0; k < 3; ++k) v.push_back(ob.offset[k]);
-    v.push_back(ob.sin_theta); v.push_back(ob.cos_theta);
+    Signature g{};
+    int n = 0;
+    auto push = [&](double x) { g.v[n++] = x; };
+    push((double)ob.flags);
+    for (int k = 0; k < 3; ++k) push(ob.offset[k]);
+    push(ob.sin_theta); push(ob.cos_theta);
     const rt_shape& sh = s_.shapes[ob.geom];
-    v.push_back((double)sh.tag);
-    for (int k = 0; k < 9; ++k) v.push_back(sh.p[k]);
+    push((double)sh.tag);
+    for (int k = 0; k < 9; ++k) push(sh.p[k]);
     const rt_material& m = s_.materials[sh.material];
-    v.push_back((double)m.tag);
-    for (int k = 0; k < 3; ++k) v.push_back(m.albedo[k]);
-    v.push_back(m.fuzz); v.push_back(m.ir);
+    push((double)m.tag);
+    for (int k = 0; k < 3; ++k) push(m.albedo[k]);
+    push(m.fuzz); push(m.ir);
     if (m.texture >= 0 && m.texture < s_.n_textures) {
       const rt_texture& t = s_.textures[m.texture];
-      v.push_back((double)t.tag);
-      if (t.tag == RT_TEX_SOLID) for (int k = 0; k < 3; ++k) v.push_back(t.color[k]);
-      else v.push_back((double)m.texture);  // other textures: the same record only
+      push((double)t.tag);
+      if (t.tag == RT_TEX_SOLID) for (int k = 0; k < 3; ++k) push(t.color[k]);
+      else push((double)m.texture);  // other textures: the same record only
     } else {
-      v.push_back(-1.0);
+      push(-1.0);
     }
-    return v;
+    return g;  // 26 values at most; the rest stays zero
   }
 
   // A sphere of negative radius (the hollow-glass trick, src/scenes.rs:235-239) reports an inverted box (src/sphere.rs:75-81),
@@ -206,9 +228,9 @@ class FastTreeBuilder {
     return g;
   }
 
-  int build_node(std::vector<Node>& nodes, std::vector<int>& ids, const std::vector<Box3d>& boxes, int lo, int hi) {
-    const int me = (int)nodes.size();
-    nodes.push_back(Node{});
+  // A subtree over k objects has 2k - 1 nodes: the node of ids[lo, hi) sits at `me`, its first subtree right behind it and the
+  // second one behind that, so disjoint subtrees write disjoint parts of `nodes` and the top levels can be split over threads.
+  void build_node(std::vector<Node>& nodes, std::vector<int>& ids, const std::vector<Box3d>& boxes, int lo, int hi, int me, int spawn_depth) {
     Box3d bb, cb;
     bb.reset(); cb.reset();
     for (int k = lo; k < hi; ++k) {
@@ -219,7 +241,12 @@ class FastTreeBuilder {
       cb.grow(c);
     }
     nodes[(size_t)me].box = bb;
-    if (hi - lo == 1) { nodes[(size_t)me].obj = ids[(size_t)lo]; return me; }
+    if (hi - lo == 1) {
+      const int o = ids[(size_t)lo];
+      nodes[(size_t)me].obj = o;
+      nodes[(size_t)me].n_links = 1 + (has_guard(o) ? 1 : 0) + ((!twice_.empty() && twice_[(size_t)o]) ? 1 : 0);
+      return;
+    }
     constexpr int kBins = 16;
     double best_cost = std::numeric_limits<double>::infinity();
     int best_axis = -1, best_split = -1;
@@ -266,8 +293,16 @@ class FastTreeBuilder {
       mid = (int)(it - ids.begin());
       if (mid == lo || mid == hi) mid = (lo + hi) / 2;
     }
-    int l = build_node(nodes, ids, boxes, lo, mid);
-    int r = build_node(nodes, ids, boxes, mid, hi);
+    int l = me + 1, r = me + 2 * (mid - lo);
+    if (spawn_depth > 0 && hi - lo >= 8192) {
+      std::thread other([&, r] { build_node(nodes, ids, boxes, mid, hi, r, spawn_depth - 1); });
+      build_node(nodes, ids, boxes, lo, mid, l, spawn_depth - 1);
+      other.join();
+    } else {
+      build_node(nodes, ids, boxes, lo, mid, l, 0);
+      build_node(nodes, ids, boxes, mid, hi, r, 0);
+    }
+    nodes[(size_t)me].n_links = 1 + nodes[(size_t)l].n_links + nodes[(size_t)r].n_links;
     // The walk visits children in a fixed order, so the one nearer to the camera goes first: camera rays (a quarter to a half
     // of all rays) then find their hit early and skip what lies behind it; for the other rays the order is as good as any.
     if (!std::getenv("RTAMD_NO_CAMERA_ORDER")) {
@@ -284,7 +319,6 @@ class FastTreeBuilder {
     }
     nodes[(size_t)me].left = l;
     nodes[(size_t)me].right = r;
-    return me;
   }
 
   uint32_t leaf_word(int obj) const {
@@ -318,32 +352,47 @@ class FastTreeBuilder {
     }
     for (int k = 0; k < 3; ++k) { l.bmin[k] = nd.box.mn[k]; l.bmax[k] = nd.box.mx[k]; }
     out.push_back(l);
-    // children in visiting order right behind their parent: left subtree, then right subtree
+    // children in visiting order right behind their parent: first subtree, then second subtree
     const int left_first = me + 1;
-    // the right subtree's first index is only known after the left one has been emitted: emit left with a placeholder, patch after
-    const size_t before = out.size();
-    (void)emit(nodes, nd.left, -2, depth + 1, tree, out);
-    const int right_first = (int)out.size();
+    const int right_first = left_first + nodes[(size_t)nd.left].n_links;
+    (void)emit(nodes, nd.left, right_first, depth + 1, tree, out);
     (void)emit(nodes, nd.right, next, depth + 1, tree, out);
-    for (size_t k = before; k < (size_t)right_first; ++k)
-      if (out[k].miss == -2) out[k].miss = right_first;
     out[(size_t)me].hit = (uint32_t)left_first;
     return me;
   }
 
   void emit_tree(const std::vector<int>& objs_in_order, int tree, std::vector<TmpLink>& out, Box3d& root_box) {
     // copies: keep the last visited one
-    std::map<std::vector<double>, int> last;
+    // open-addressing table of (hash, last object with that signature)
+    const bool timing = std::getenv("RTAMD_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+      if (!timing) return;
+      auto now = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "  own tree %d: %-22s %.3f s\n", tree, what, std::chrono::duration<double>(now - t_last).count());
+      t_last = now;
+    };
+    size_t cap = 16;
+    while (cap < 2 * objs_in_order.size()) cap <<= 1;
+    struct Slot { uint64_t hash; int obj; };
+    std::vector<Slot> table(cap, Slot{0, -1});
+    std::vector<int> slot_of((size_t)s_.n_objects, -1);
     std::vector<int> keep;
     for (int o : objs_in_order) {
       const rt_object& ob = s_.objects[o];
       if (ob.flags & (RT_OBJ_MEDIUM | RT_OBJ_SUB_BVH)) { keep.push_back(o); continue; }
-      last[signature(o)] = o;
+      const Signature g = signature(o);
+      const uint64_t h = (uint64_t)SignatureHash()(g);
+      size_t k = (size_t)h & (cap - 1);
+      while (table[k].obj >= 0 && !(table[k].hash == h && signature(table[k].obj) == g)) k = (k + 1) & (cap - 1);
+      table[k] = Slot{h, o};  // a later copy takes the place of an earlier one
+      slot_of[(size_t)o] = (int)k;
     }
+    mark("copies");
     for (int o : objs_in_order) {
       const rt_object& ob = s_.objects[o];
       if (ob.flags & (RT_OBJ_MEDIUM | RT_OBJ_SUB_BVH)) continue;
-      if (last[signature(o)] != o) continue;
+      if (table[(size_t)slot_of[(size_t)o]].obj != o) continue;
       if (has_guard(o)) {
         // alone in a one-object node, the inverted box IS the node's box, and the reference's box test (src/aabb.rs:30-46) fails
         // for every ray: the sphere is never tested there, so it is not part of this tree either
@@ -352,13 +401,20 @@ class FastTreeBuilder {
       }
       keep.push_back(o);
     }
+    if (keep.empty() && !objs_in_order.empty()) keep.push_back(objs_in_order.back());  // a tree needs a leaf (all objects unreachable: keep one)
     std::vector<Box3d> boxes((size_t)s_.n_objects);
     for (int o : keep) boxes[(size_t)o] = object_box(o);
-    std::vector<Node> nodes;
-    nodes.reserve(keep.size() * 2);
-    (void)build_node(nodes, keep, boxes, 0, (int)keep.size());
+    std::vector<Node> nodes(keep.size() * 2 - 1);
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char* e = std::getenv("OMP_NUM_THREADS")) hw = std::min<unsigned>(hw ? hw : 1u, (unsigned)std::max(1, atoi(e)));
+    int spawn_depth = 0;
+    while ((1u << (spawn_depth + 1)) <= std::max(1u, hw) && spawn_depth < 6) ++spawn_depth;
+    mark("boxes");
+    build_node(nodes, keep, boxes, 0, (int)keep.size(), 0, spawn_depth);
+    mark("split");
     root_box = nodes[0].box;
     out.clear();
+    out.reserve((size_t)nodes[0].n_links + 2);
     if (nodes[0].obj >= 0) {
       // a single object: give it a box entry so that the walk starts on a box, as every other tree does
       TmpLink b{};
@@ -378,6 +434,7 @@ class FastTreeBuilder {
       return;
     }
     (void)emit(nodes, 0, LINK_END, 0, tree, out);
+    mark("threaded list");
   }
 };
 

@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "host_util.h"
@@ -258,37 +260,78 @@ struct SceneData {
     if (a == b) return std::signbit(a) && !std::signbit(b);
     return a < b;
   }
-  int build_bvh(std::vector<int> objs, double time0, double time1, Pcg32& axis_rng) {
-    int axis = (int)axis_rng.range_u32_inclusive(0, 2);
-    int me = (int)nodes.size();
-    nodes.push_back(rt_bvh_node{});
-    auto key = [&](int o) { return object_box(o, 0.0, 0.0).mn[axis]; };  // src/bvh.rs:83-94
+  // The tree the reference would build, built faster.  The recursion of the reference draws a node's axis, sorts the node's
+  // objects, then builds the left half completely before the right one: a node's number (and the position of its axis draw in
+  // the random sequence) is its preorder index, and how many nodes a subtree has depends only on how many objects it holds.
+  // So all axes are drawn up front, the sort keys (bounding_box(0,0).min per axis, src/bvh.rs:83-94) are computed once per object
+  // instead of once per comparison, the halves are sorted in place (the copies the reference makes are the sorted halves), and
+  // subtrees are handed to threads: every node still gets the axis, the order and the index it has in the reference.
+  static size_t bvh_node_count(size_t n) { return n <= 2 ? 1 : 1 + bvh_node_count(n / 2) + bvh_node_count(n - n / 2); }
+  struct BvhJob {
+    std::vector<int> order;          // object indices; each node sorts its own span
+    std::vector<uint8_t> axis;       // per node of this tree, preorder
+    std::vector<double> key[3];      // per object index
+    double time0, time1;
+    int base;                        // index of the tree's first node in `nodes`
+  };
+  void build_span(BvhJob& job, size_t lo, size_t hi, int me, int spawn_depth) {
+    const int axis = job.axis[(size_t)(me - job.base)];
+    const std::vector<double>& key = job.key[axis];
+    int* o = job.order.data();
+    const size_t n = hi - lo;
     int left, right;
-    size_t n = objs.size();
     if (n == 1) {
-      left = right = ~objs[0];
+      left = right = ~o[lo];
     } else if (n == 2) {
-      if (total_less(key(objs[0]), key(objs[1]))) { left = ~objs[0]; right = ~objs[1]; }
-      else { left = ~objs[1]; right = ~objs[0]; }
+      if (total_less(key[(size_t)o[lo]], key[(size_t)o[lo + 1]])) { left = ~o[lo]; right = ~o[lo + 1]; }
+      else { left = ~o[lo + 1]; right = ~o[lo]; }
     } else {
-      std::stable_sort(objs.begin(), objs.end(), [&](int a, int b) { return total_less(key(a), key(b)); });
-      size_t mid = n / 2;
-      left = build_bvh(std::vector<int>(objs.begin(), objs.begin() + mid), time0, time1, axis_rng);
-      right = build_bvh(std::vector<int>(objs.begin() + mid, objs.end()), time0, time1, axis_rng);
+      std::stable_sort(o + lo, o + hi, [&](int a, int b) { return total_less(key[(size_t)a], key[(size_t)b]); });
+      const size_t mid = lo + n / 2;
+      left = me + 1;
+      right = me + 1 + (int)bvh_node_count(mid - lo);
+      if (spawn_depth > 0 && n >= 4096) {
+        std::thread other([&, right] { build_span(job, mid, hi, right, spawn_depth - 1); });
+        build_span(job, lo, mid, left, spawn_depth - 1);
+        other.join();
+      } else {
+        build_span(job, lo, mid, left, 0);
+        build_span(job, mid, hi, right, 0);
+      }
     }
     auto child_box = [&](int c) {
       if (c >= 0) {
         Box3 b;
-        for (int k = 0; k < 3; ++k) { b.mn[k] = nodes[c].bmin[k]; b.mx[k] = nodes[c].bmax[k]; }
+        for (int k = 0; k < 3; ++k) { b.mn[k] = nodes[(size_t)c].bmin[k]; b.mx[k] = nodes[(size_t)c].bmax[k]; }
         return b;
       }
-      return object_box(~c, time0, time1);
+      return object_box(~c, job.time0, job.time1);
     };
     Box3 b = surrounding(child_box(left), child_box(right));
-    rt_bvh_node& nd = nodes[me];
+    rt_bvh_node& nd = nodes[(size_t)me];
     for (int k = 0; k < 3; ++k) { nd.bmin[k] = b.mn[k]; nd.bmax[k] = b.mx[k]; }
     nd.left = left; nd.right = right;
-    return me;
+  }
+  int build_bvh(std::vector<int> objs, double time0, double time1, Pcg32& axis_rng) {
+    BvhJob job;
+    job.time0 = time0; job.time1 = time1;
+    job.base = (int)nodes.size();
+    const size_t n_nodes = bvh_node_count(objs.size());
+    job.axis.resize(n_nodes);
+    for (size_t i = 0; i < n_nodes; ++i) job.axis[i] = (uint8_t)axis_rng.range_u32_inclusive(0, 2);
+    for (int k = 0; k < 3; ++k) job.key[k].assign(objects.size(), 0.0);
+    for (int o : objs) {
+      const Box3 b = object_box(o, 0.0, 0.0);
+      for (int k = 0; k < 3; ++k) job.key[k][(size_t)o] = b.mn[k];
+    }
+    job.order = std::move(objs);
+    nodes.resize(nodes.size() + n_nodes);  // no reallocation while threads write their nodes
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char* e = std::getenv("OMP_NUM_THREADS")) hw = std::min<unsigned>(hw ? hw : 1u, (unsigned)std::max(1, atoi(e)));
+    int depth = 0;
+    while ((1u << (depth + 1)) <= std::max(1u, hw) && depth < 6) ++depth;  // 2^depth threads at the deepest split
+    build_span(job, 0, job.order.size(), job.base, depth);
+    return job.base;
   }
 
   void set_camera(D3 look_from, D3 look_at, D3 v_up, double vfov_degrees, double aspect, double aperture, double focus_dist,

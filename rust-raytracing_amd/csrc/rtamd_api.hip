@@ -1,11 +1,14 @@
 // C ABI of librtamd.so (declared in include/rtamd.h): context, scene validation and upload, dispatch to the
 // per-precision render code.  No kernels in this file.
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 
 #include "accel_build.h"
 #include "context.h"
 
 #include <mutex>
+#include <thread>
 
 namespace rti {
 thread_local std::string g_err;
@@ -241,6 +244,15 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   free_scene(c);
 
+  // RTAMD_TIMING=1: seconds spent in each stage of the upload, on stderr
+  const bool timing = std::getenv("RTAMD_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (!timing) return;
+    auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "rt_upload_scene: %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
   // threaded links: the top-level tree first, then every nested tree
   LinkBuilder lb(*s);
   int root = lb.node(s->root_node, LINK_END, 0, 0);
@@ -249,6 +261,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   for (int i = 0; i < s->n_objects && lb.err.empty(); ++i)
     if (s->objects[i].flags & RT_OBJ_SUB_BVH) sub_root[i] = lb.node(s->objects[i].geom, LINK_END, 0, tree++);
   if (!lb.err.empty()) return fail(lb.err.find("not supported") != std::string::npos ? RT_E_UNSUPPORTED : RT_E_INVALID, "rt_upload_scene: " + lb.err);
+  mark("reference tree -> links");
   // Which preset covers this scene?
   uint32_t feat = 0;
   bool has_nested = false;
@@ -309,14 +322,16 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
       if (order.size() != in.size()) order_err = "rt_upload_scene: internal error while ordering links";
     }
     if (!uniform || !order_err.empty()) {
+      // stable counting sort by (nested?, depth)
       order.resize(in.size());
-      for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-      std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-        const TmpLink &x = in[a], &y = in[b];
-        int kx = x.tree != 0, ky = y.tree != 0;
-        if (kx != ky) return kx < ky;
-        return x.depth < y.depth;
-      });
+      int max_depth = 0;
+      for (const TmpLink& l : in) max_depth = std::max(max_depth, l.depth);
+      const size_t n_keys = 2 * (size_t)(max_depth + 1);
+      auto key = [&](const TmpLink& l) { return (size_t)(l.tree != 0) * (size_t)(max_depth + 1) + (size_t)l.depth; };
+      std::vector<size_t> first(n_keys + 1, 0);
+      for (const TmpLink& l : in) ++first[key(l) + 1];
+      for (size_t k = 0; k < n_keys; ++k) first[k + 1] += first[k];
+      for (size_t i = 0; i < in.size(); ++i) order[first[key(in[i])]++] = (int)i;
     }
     std::vector<int> new_index(order.size());
     for (size_t i = 0; i < order.size(); ++i) new_index[order[i]] = (int)i;
@@ -396,12 +411,16 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   scene32.objects = objects32.data();
   scene32.shapes = shapes32.data();
   scene32.n_shapes = (int32_t)shapes32.size();
+  mark("preset, nested trees");
   if (own_tree) {
     FastTreeBuilder ftb(scene32);
     ftb.build(lb.links, root, sub_root, dissolved, fast_links, fast_root, fast_sub_root);
+    mark("own tree");
     fast_links = reorder(fast_links, fast_root, fast_sub_root);
+    mark("own tree: storage order");
   }
   std::vector<TmpLink> links = reorder(lb.links, root, sub_root);
+  mark("reference tree: storage order");
   if (!order_err.empty()) return fail(RT_E_INVALID, order_err);
 
   // images
@@ -418,12 +437,30 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     HIP_TRY(hipMalloc((void**)&c->d_images, sizeof(DImage) * host_images.size()));
     HIP_TRY(hipMemcpy(c->d_images, host_images.data(), sizeof(DImage) * host_images.size(), hipMemcpyHostToDevice));
   }
+  // the three images are independent of one another: the double-precision ones are built on threads of their own
+  const bool want_own64 = own_tree && !std::getenv("RTAMD_NO_F64_OWN_TREE");
+  int rc_sd = RT_OK, rc_own = RT_OK;
+  std::string err_sd, err_own;
+  const int device = c->device;
+  std::thread t_sd([&] {
+    if (hipSetDevice(device) != hipSuccess) { rc_sd = RT_E_HIP; err_sd = "hipSetDevice failed"; return; }
+    rc_sd = build_image<double>(c, *s, links, root, sub_root, preset, c->sd);
+    if (rc_sd != RT_OK) err_sd = g_err;
+  });
+  // RT_F64_OWN_TREE: the library's tree once more, in double (the presets without nested-walk code exist in single only)
+  std::thread t_own([&] {
+    if (!want_own64) return;
+    if (hipSetDevice(device) != hipSuccess) { rc_own = RT_E_HIP; err_own = "hipSetDevice failed"; return; }
+    rc_own = build_image<double>(c, scene32, fast_links, fast_root, fast_sub_root, preset32 == PRESET_FLATALL_LDS ? PRESET_ALL_LDS : preset32, c->sd_own);
+    if (rc_own != RT_OK) err_own = g_err;
+  });
   rc = own_tree ? build_image<float>(c, scene32, fast_links, fast_root, fast_sub_root, preset32, c->sf)
                 : build_image<float>(c, *s, links, root, sub_root, preset, c->sf);
-  if (rc == RT_OK) rc = build_image<double>(c, *s, links, root, sub_root, preset, c->sd);
-  // RT_F64_OWN_TREE: the library's tree once more, in double (the presets without nested-walk code exist in single only)
-  if (rc == RT_OK && own_tree && !std::getenv("RTAMD_NO_F64_OWN_TREE"))
-    rc = build_image<double>(c, scene32, fast_links, fast_root, fast_sub_root, preset32 == PRESET_FLATALL_LDS ? PRESET_ALL_LDS : preset32, c->sd_own);
+  t_sd.join();
+  t_own.join();
+  if (rc == RT_OK && rc_sd != RT_OK) rc = fail(rc_sd, err_sd);
+  if (rc == RT_OK && rc_own != RT_OK) rc = fail(rc_own, err_own);
+  mark("f32, f64, f64 own-tree images");
   if (rc != RT_OK) { free_scene(c); return rc; }
   c->has_scene = true;
   return RT_OK;
