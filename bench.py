@@ -240,7 +240,7 @@ def main():
         issue = None
         try:  # counters of the same kernel on this frame, collected by tools/profile_round.sh (separate rocprofv3 passes)
             with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
-                t = json.load(f).get("%s_%s_%s" % (args.scene, name, "persistent" if persistent else args.pipeline))
+                t = json.load(f).get("%s_%s_%s" % (args.scene, leg["name"], "persistent" if persistent else args.pipeline))
             if t is not None:  # bytes per frame at the profiled sample count -> per launch of this run
                 traffic = t["bytes_per_frame"] * (args.spp / t["spp"]) * (s1 - s0) / args.spp / (leg["launches"] / max(1, args.steps))
                 with open(os.path.join(REPO, "profiles", "%s.json" % t["from"])) as f:
