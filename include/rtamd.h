@@ -203,7 +203,9 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* scene);
 /* The sample loop (src/render.rs:224-237) for samples [sample_begin, sample_end) of every pixel:
  * adds linear radiance sums into `accum_dev`, a DEVICE buffer of width*height*4 floats (F32) or
  * doubles (F64), pixel-major, row 0 on top, channel 3 unused.  NULL = the context's own buffer
- * (zeroed at the start of the call).  Returns with the stream idle. */
+ * (zeroed at the start of the call).  Returns with the stream idle.  The buffer must be ordinary device memory (hipMalloc):
+ * the sums are added with hardware floating-point atomics, which host-mapped and managed memory drop; such a buffer is refused
+ * with RT_E_INVALID. */
 int rt_render_accum(rt_context* ctx, const rt_render_params* params, void* accum_dev, rt_stats* stats);
 
 /* color_to_pixel (src/color.rs:14-33) over an accumulation buffer (NULL = the context's own):

@@ -446,20 +446,28 @@ RT_DEV bool traverse_flat(const SceneView<R, C>& sv, int start, const Ray<R>& ra
           }
         }
       }
-      if (plain) {
+      // the shape test proper.  Double precision: on the world ray for a bare shape and on the holder's local ray otherwise, as two
+      // calls, so that the bare shapes - most leaves - do not pay for copies of the ray into the registers the transformed ones use
+      auto shape_test = [&](const Ray<R>& r, const RayRcp<R>& rr) {
         switch (s.tag) {
           case SH_SPHERE: if constexpr (C::has(F_SPHERE)) {
-            ok = sphere_roots(V3<R>(s.p[0], s.p[1], s.p[2]), local, s.p[3], t_min, closest, t, self);
+            ok = sphere_roots(V3<R>(s.p[0], s.p[1], s.p[2]), r, s.p[3], t_min, closest, t, self);
           } break;
           case SH_MOVING: if constexpr (C::has(F_MOVING)) {
-            ok = sphere_roots(moving_center(s, local.time), local, s.p[6], t_min, closest, t, self);
+            ok = sphere_roots(moving_center(s, r.time), r, s.p[6], t_min, closest, t, self);
           } break;
-          case SH_RECT_XY: if constexpr (C::has(F_RECT)) { ok = rect_fast<2>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], local, rl, t_min, closest, t) & !self; } break;
-          case SH_RECT_XZ: if constexpr (C::has(F_RECT)) { ok = rect_fast<1>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], local, rl, t_min, closest, t) & !self; } break;
-          case SH_RECT_YZ: if constexpr (C::has(F_RECT)) { ok = rect_fast<0>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], local, rl, t_min, closest, t) & !self; } break;
-          case SH_BOX: if constexpr (C::has(F_BOX)) { ok = box_slab_t<R>(s, local, rl, t_min, closest, self ? org_side : -2, t, side); } break;
+          case SH_RECT_XY: if constexpr (C::has(F_RECT)) { ok = rect_fast<2>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], r, rr, t_min, closest, t) & !self; } break;
+          case SH_RECT_XZ: if constexpr (C::has(F_RECT)) { ok = rect_fast<1>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], r, rr, t_min, closest, t) & !self; } break;
+          case SH_RECT_YZ: if constexpr (C::has(F_RECT)) { ok = rect_fast<0>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], r, rr, t_min, closest, t) & !self; } break;
+          case SH_BOX: if constexpr (C::has(F_BOX)) { ok = box_slab_t<R>(s, r, rr, t_min, closest, self ? org_side : -2, t, side); } break;
           default: break;
         }
+      };
+      if constexpr (sizeof(R) == sizeof(double)) {  // measured: +1.4 % on the headline frame in double, -2.5 % in single (one call there)
+        if (word & LEAF_SIMPLE) shape_test(ray, ri);
+        else if (plain) shape_test(local, rl);
+      } else {
+        if (plain) shape_test(local, rl);
       }
       closest = ok ? t : closest;
       best_leaf = ok ? obj : best_leaf;

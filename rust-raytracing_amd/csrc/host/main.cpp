@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
   rth_render_config cfg{};
   cfg.scene.aux_seed = 1;
   cfg.scene.bvh_seed = 7;
-  cfg.precision = RT_PRECISION_F32;
+  cfg.precision = RT_PRECISION_F64;  // the reference's arithmetic; --precision f32 is the tolerance mode
   cfg.pipeline = RT_PIPELINE_AUTO;
   auto need = [&](int& i) -> const char* {
     if (i + 1 >= argc) { std::fprintf(stderr, "error: a value is required for '%s'\n", argv[i]); std::exit(2); }
@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
     else if (a == "--device") cfg.device = std::atoi(need(i));
     else if (a == "--earth") cfg.scene.earth_path = need(i);
     else if (a == "--mega-grid") cfg.scene.mega_grid = std::atoi(need(i));
-    else if (a == "--precision") cfg.precision = std::strcmp(need(i), "f64") == 0 ? RT_PRECISION_F64 : RT_PRECISION_F32;
+    else if (a == "--precision") cfg.precision = std::strcmp(need(i), "f32") == 0 ? RT_PRECISION_F32 : RT_PRECISION_F64;
     else if (a == "--pipeline") {
       const char* v = need(i);
       cfg.pipeline = !std::strcmp(v, "fused") ? RT_PIPELINE_FUSED : !std::strcmp(v, "sorted") ? RT_PIPELINE_SORTED : RT_PIPELINE_AUTO;

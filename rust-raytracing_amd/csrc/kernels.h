@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : (C::has(F
   // done, add its sum to the pixel and take a new chunk - then ONE evaluation of Philox serves the scatter draw of the continuing
   // lanes and the pixel jitter of the starting ones, and all lanes trace their next ray.
   for (;;) {
-    RT_STAMP(6);
+    RT_STAMP(0);
     bool to_scatter = false;
     bool absorbed = false;
     if (active) {
@@ -375,6 +375,7 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : (C::has(F
         }
       }
     }
+    RT_STAMP(6);
     if constexpr (CHUNKED) {
       const bool was_active = active;
       feeder.template refill<false, FIXED_GRAB>(sc, fp, total_paths, path_cursor, st, bounce, active);
@@ -391,6 +392,7 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : (C::has(F
     RT_STAMP(0);
     if (__ballot(active) == 0ull) break;
     const PrimedStream rng(Stream(fp.seed, st.pixel, st.sample, bounce, to_scatter ? STAGE_SCATTER : STAGE_CAMERA), to_scatter ? resume : 0u, kBlocksPerTurn);
+    RT_STAMP(7);
     if (to_scatter) {
       V3<R> emitted, attenuation;
       Ray<R> scattered;
@@ -404,10 +406,10 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : (C::has(F
         if constexpr (CHUNKED) absorbed = !alive;
         else active = alive;
       }
-    } else if (active) {
-      st.ray = primary_ray<R, C::relaxed()>(sc.camera, fp.width, fp.height, st.pixel, rng);
     }
     RT_STAMP(2);
+    if (!to_scatter && active) st.ray = primary_ray<R, C::relaxed()>(sc.camera, fp.width, fp.height, st.pixel, rng);
+    RT_STAMP(1);
     // an absorbed path (a metal's scattered ray below the surface, src/material.rs:88-90) ends here: it sits out this trace as a
     // miss that adds nothing, and the next turn closes it like any other ended path
     const bool go = active && resume == 0u && !absorbed;

@@ -297,8 +297,8 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
       for (size_t w = 16; w + 8 <= kRayCountWords; w += 8)
         for (int k = 0; k < 8; ++k) st[k] += (double)all[w + k];
       for (int k = 0; k < 8; ++k) tot += st[k];
-      fprintf(stderr, "[stamps] persistent, wave cycles by phase (refill, trace rest, shade+accumulate, walk setup + root box, leaf loop, finalize, loop top):");
-      for (int k = 0; k < 7; ++k) fprintf(stderr, " %.1f%%", 100.0 * st[k] / tot);
+      fprintf(stderr, "[stamps] persistent, wave cycles by phase (0 refill, 1 primary rays + trace rest, 2 scatter, 3 walk setup, 4 leaf loop, 5 finalize, 6 close ended paths, 7 Philox):");
+      for (int k = 0; k < 8; ++k) fprintf(stderr, " [%d] %.1f%%", k, 100.0 * st[k] / tot);
       fprintf(stderr, "  %.0f cycles per wave iteration of %.1f rays\n", tot / ((double)rays / 64.0) , 64.0);
     }
 #endif
@@ -418,8 +418,8 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
       for (int k = 0; k < 8; ++k) st[1 + k] += all[w + k];
     double tot = 0;
     for (int k = 1; k < 9; ++k) tot += (double)st[k];
-    fprintf(stderr, "[stamps] wave cycles by phase (take, load, trace, shade, accumulate, slot, store):");
-    for (int k = 1; k < 8; ++k) fprintf(stderr, " %.1f%%", 100.0 * (double)st[k] / tot);
+    fprintf(stderr, "[stamps] wave cycles by phase (persistent kernel: 0 refill, 1 trace, 2 primary rays, 3 close ended paths, 4 Philox, 5 scatter, 6 loop):");
+    for (int k = 1; k < 8; ++k) fprintf(stderr, " [%d] %.1f%%", k - 1, 100.0 * (double)st[k] / tot);
     fprintf(stderr, "  total %.3e cycles, %.0f per wave pass of 64 rays\n", tot, tot / ((double)rays / 64.0));
   }
 #endif

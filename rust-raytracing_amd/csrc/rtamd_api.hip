@@ -172,6 +172,19 @@ int validate(const rt_scene_desc& s, std::string& err) {
   return RT_OK;
 }
 
+// The radiance sums are added with hardware floating-point atomics, which act on ordinary device memory only: on host-mapped or
+// managed (fine-grained) memory they are silently dropped and the image comes out black.  Such a buffer is refused.
+int check_device_buffer(const void* p, const char* who) {
+  hipPointerAttribute_t at{};
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(RT_E_INVALID, std::string(who) + ": accum_dev is not a device pointer");
+  }
+  if (at.type != hipMemoryTypeDevice)
+    return fail(RT_E_INVALID, std::string(who) + ": accum_dev must be ordinary device memory (hipMalloc); host-mapped and managed memory drop the atomic adds");
+  return RT_OK;
+}
+
 int check_render_params(const rt_context* c, const rt_render_params* p) {
   if (!c) return fail(RT_E_INVALID, "context is NULL");
   if (!p) return fail(RT_E_INVALID, "params is NULL");
@@ -470,6 +483,8 @@ int rt_render_accum(rt_context* c, const rt_render_params* p, void* accum_dev, r
   int rc = check_render_params(c, p);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(c->device));
+  if (accum_dev)
+    if (int bad = check_device_buffer(accum_dev, "rt_render_accum")) return bad;
   if (stats) std::memset(stats, 0, sizeof(*stats));
   rt_render_params q = *p;
   q.precision = select_tree(c, p->precision);
@@ -589,6 +604,7 @@ int rt_render_noalloc(rt_context* c, const rt_render_params* p, void* accum_dev,
   if (!c->scratch) return fail(RT_E_HIP, "rt_render_noalloc: no scratch address for this device");
   auto t0 = std::chrono::steady_clock::now();
   HIP_TRY(hipSetDevice(c->device));
+  if (int bad = check_device_buffer(accum_dev, "rt_render_noalloc")) return bad;  // a query, not an allocation
   if (stats) std::memset(stats, 0, sizeof(*stats));
   rt_render_params q = *p;
   q.precision = select_tree(c, p->precision);

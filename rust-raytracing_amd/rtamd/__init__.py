@@ -253,7 +253,7 @@ class Context:
         p.precision, p.pipeline, p.samples_per_pass, p.seed = precision, pipeline, samples_per_pass, seed
         return p
 
-    def render(self, s_begin=0, s_end=None, precision=F32, pipeline=PIPELINE_AUTO, seed=0, samples_per_pass=0, depth=None, width=0,
+    def render(self, s_begin=0, s_end=None, precision=F64, pipeline=PIPELINE_AUTO, seed=0, samples_per_pass=0, depth=None, width=0,
                height=0, want_accum=True, want_rgb=True):
         """rt_render: returns (rgb8[H,W,3] or None, accum[H,W,3] float64 or None, stats dict)."""
         if s_end is None:
@@ -265,7 +265,7 @@ class Context:
         _check(self.L.rt_render(self.h, C.byref(p), _p(rgb) if want_rgb else None, _p(acc) if want_accum else None, C.byref(st)))
         return rgb, acc, st.as_dict()
 
-    def render_accum(self, accum_dev_ptr, s_begin, s_end, precision=F32, pipeline=PIPELINE_AUTO, seed=0, samples_per_pass=0, depth=None,
+    def render_accum(self, accum_dev_ptr, s_begin, s_end, precision=F64, pipeline=PIPELINE_AUTO, seed=0, samples_per_pass=0, depth=None,
                      width=0, height=0):
         """rt_render_accum into a caller-owned DEVICE buffer (address as int) or the context's own (None)."""
         p = self._params(width, height, s_begin, s_end, depth, precision, pipeline, samples_per_pass, seed)
@@ -273,7 +273,7 @@ class Context:
         _check(self.L.rt_render_accum(self.h, C.byref(p), C.c_void_p(accum_dev_ptr) if accum_dev_ptr else None, C.byref(st)))
         return st.as_dict()
 
-    def render_noalloc(self, accum_dev_ptr, rgb_out, s_begin, s_end, precision=F32, pipeline=PIPELINE_AUTO, seed=0, depth=None, width=0, height=0):
+    def render_noalloc(self, accum_dev_ptr, rgb_out, s_begin, s_end, precision=F64, pipeline=PIPELINE_AUTO, seed=0, depth=None, width=0, height=0):
         """rt_render_noalloc: whole frame into the caller's DEVICE sums (address as int) and host RGB8 array; nothing is allocated."""
         p = self._params(width, height, s_begin, s_end, depth, precision, pipeline, 0, seed)
         assert rgb_out.dtype == np.uint8 and rgb_out.size == p.width * p.height * 3 and rgb_out.flags["C_CONTIGUOUS"]
@@ -281,7 +281,7 @@ class Context:
         _check(self.L.rt_render_noalloc(self.h, C.byref(p), C.c_void_p(accum_dev_ptr), _p(rgb_out), C.byref(st)))
         return st.as_dict()
 
-    def progress_begin(self, s_begin=0, s_end=None, precision=F32, pipeline=PIPELINE_AUTO, seed=0, depth=None, width=0, height=0):
+    def progress_begin(self, s_begin=0, s_end=None, precision=F64, pipeline=PIPELINE_AUTO, seed=0, depth=None, width=0, height=0):
         """rt_progress_begin: fixes the frame of a progressive render."""
         p = self._params(width, height, s_begin, self.scene.spp if s_end is None else s_end, depth, precision, pipeline, 0, seed)
         _check(self.L.rt_progress_begin(self.h, C.byref(p)))
@@ -302,18 +302,18 @@ class Context:
     def comm_destroy(self):
         _check(self.L.rt_comm_destroy(self.h))
 
-    def reduce_accum(self, accum_dev_ptr, width, height, precision=F32, root=0):
+    def reduce_accum(self, accum_dev_ptr, width, height, precision=F64, root=0):
         """rt_reduce_accum: sums the ranks' DEVICE buffers (address as int, or None for the context's own) onto `root`."""
         _check(self.L.rt_reduce_accum(self.h, C.c_void_p(accum_dev_ptr) if accum_dev_ptr else None, width, height, precision, root))
 
-    def resolve(self, accum_dev_ptr, width, height, spp, precision=F32, out=None):
+    def resolve(self, accum_dev_ptr, width, height, spp, precision=F64, out=None):
         """rt_resolve; `out` (uint8 [height, width, 3], e.g. a view of pinned memory) is filled in place when given."""
         rgb = out if out is not None else np.zeros((height, width, 3), dtype=np.uint8)
         assert rgb.dtype == np.uint8 and rgb.shape == (height, width, 3) and rgb.flags["C_CONTIGUOUS"]
         _check(self.L.rt_resolve(self.h, C.c_void_p(accum_dev_ptr) if accum_dev_ptr else None, width, height, spp, precision, _p(rgb)))
         return rgb
 
-    def read_accum(self, accum_dev_ptr, width, height, precision=F32):
+    def read_accum(self, accum_dev_ptr, width, height, precision=F64):
         out = np.zeros((height, width, 3), dtype=np.float64)
         _check(self.L.rt_read_accum(self.h, C.c_void_p(accum_dev_ptr) if accum_dev_ptr else None, width, height, precision, _p(out)))
         return out
@@ -399,7 +399,7 @@ def load_ppm(path):
     return out
 
 
-def render_and_save(scene, output, device=0, precision=F32, pipeline=PIPELINE_AUTO, seed=0, quiet=True, **scene_kw):
+def render_and_save(scene, output, device=0, precision=F64, pipeline=PIPELINE_AUTO, seed=0, quiet=True, **scene_kw):
     """render_and_save (src/render.rs:278-284) through the host library."""
     _, H = load_libraries()
     cfg = RenderConfig()

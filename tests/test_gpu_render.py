@@ -220,6 +220,25 @@ def test_error_paths(rtamd):
     ctx.close()
 
 
+def test_host_memory_is_refused_as_accumulation_buffer(gpu, rtamd):
+    """The radiance sums are hardware floating-point atomics, which page-locked host memory (and managed memory) silently drops:
+    such a buffer is refused instead of coming back black."""
+    import torch
+    hs = rtamd.Scene("cornell-box", width=32, aspect=1.0, spp=1)
+    gpu.upload(hs)
+    pinned = torch.zeros(32 * 32 * 4, dtype=torch.float64).pin_memory()
+    with pytest.raises(rtamd.RtError) as e:
+        gpu.render_accum(pinned.data_ptr(), 0, 1, precision=rtamd.F64)
+    assert e.value.code == 1 and "device memory" in str(e.value)
+    heap = np.zeros(32 * 32 * 4)
+    with pytest.raises(rtamd.RtError) as e:
+        gpu.render_accum(heap.ctypes.data, 0, 1, precision=rtamd.F64)
+    assert e.value.code == 1  # RT_E_INVALID
+    dev = torch.zeros(32 * 32 * 4, dtype=torch.float64, device="cuda")
+    gpu.render_accum(dev.data_ptr(), 0, 1, precision=rtamd.F64)
+    assert float(dev.sum()) >= 0.0
+
+
 def test_many_perlin_tables_leave_the_small_scene_preset(gpu, rtamd, oracle):
     """A small scene whose image does not fit the 64 KiB of LDS the small-scene presets stage it in (nine Perlin tables are 100 KiB
     in double precision) must take a per-lane preset instead of failing at launch, and render the same picture."""
