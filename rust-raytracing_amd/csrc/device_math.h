@@ -179,9 +179,10 @@ RT_DEV double next_toward(double x, double lo) {
   return x == lo ? x : __longlong_as_double(__double_as_longlong(x) + ((x > lo) == (x > 0.0) ? -1ll : 1ll));
 }
 RT_DEV float u01_of(uint32_t h, uint32_t, float) { return (float)(h >> 8) * 0x1.0p-24f; }
-RT_DEV double u01_of(uint32_t h, uint32_t l, double) { return (double)((((uint64_t)h << 32) | l) >> 11) * 0x1.0p-53; }
+// (h << 32 | l) >> 11 scaled by 2^-53 = h * 2^-32 + (l >> 11) * 2^-53: a 53-bit value, so the one multiply-add is exact
+RT_DEV double u01_of(uint32_t h, uint32_t l, double) { return __builtin_fma((double)h, 0x1.0p-32, (double)(l >> 11) * 0x1.0p-53); }
 RT_DEV float m01_of(uint32_t h, uint32_t, float) { return (float)(h >> 9) * 0x1.0p-23f; }
-RT_DEV double m01_of(uint32_t h, uint32_t l, double) { return (double)((((uint64_t)h << 32) | l) >> 12) * 0x1.0p-52; }
+RT_DEV double m01_of(uint32_t h, uint32_t l, double) { return __builtin_fma((double)h, 0x1.0p-32, (double)(l >> 12) * 0x1.0p-52); }
 template <class R> RT_DEV R range_of(uint32_t h, uint32_t l, R lo, R hi) {  // half-open [lo, hi)
   R res = m01_of(h, l, (R)0) * (hi - lo) + lo;
   return res < hi ? res : next_toward(hi, lo);
@@ -238,8 +239,11 @@ RT_DEV void fields21(uint32_t w0, uint32_t w1, uint32_t& xi, uint32_t& yi, uint3
   xi = w0 >> 11; yi = ((w0 & 0x7FFu) << 10) | (w1 >> 22); zi = (w1 >> 1) & 0x1FFFFFu;
 }
 RT_DEV float coord_of(uint32_t hi21, uint32_t, float) { return (float)hi21 * 0x1.0p-20f - 1.0f; }
-RT_DEV double coord_of(uint32_t hi21, uint32_t lo31, double) {  // gen_range(-1.0..1.0) on the 52-bit mantissa hi << 31 | lo
-  return ((double)(((uint64_t)hi21 << 31) | lo31) * 0x1.0p-52) * 2.0 + -1.0;
+// gen_range(-1.0..1.0) on the 52-bit mantissa m = hi << 31 | lo: (m * 2^-52) * 2 + -1.  Every step of that is exact (m has 52
+// bits; the result is a multiple of 2^-51 in [-1, 1)), so it equals hi * 2^-20 - 1 + lo * 2^-51 formed by two multiply-adds -
+// exact as well, the first a multiple of 2^-20 in [-1, 1) - without the 64-bit integer to double conversion (four instructions).
+RT_DEV double coord_of(uint32_t hi21, uint32_t lo31, double) {
+  return __builtin_fma((double)lo31, 0x1.0p-51, __builtin_fma((double)hi21, 0x1.0p-20, -1.0));
 }
 template <class R> RT_DEV V3<R> point_of(uint32_t w0, uint32_t w1, uint32_t l0, uint32_t l1, uint32_t l2) {
   uint32_t xi, yi, zi;
@@ -274,7 +278,9 @@ template <class S> RT_DEV V3<double> random_in_unit_sphere(const S& s, double) {
       }
       w0 = (c & 1u) ? h[2] : h[0];
       w1 = (c & 1u) ? h[3] : h[1];
-      if (length_squared(point_of<double>(w0, w1, 0u, 0u, 0u)) < 1.0 + 6e-6) break;
+      // this screening runs in single precision: the 21-bit fields are exact there, and the rounding of the squared length
+      // (below 4e-7) is covered by the margin
+      if (length_squared(point_of<float>(w0, w1, 0u, 0u, 0u)) < 1.0f + 8e-6f) break;
     }
     uint32_t l[3];
     low3(w0, w1, l);
