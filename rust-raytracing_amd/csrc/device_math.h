@@ -216,7 +216,10 @@ RT_DEV uint64_t word_at(const Stream& s, uint32_t slot) {
   uint32_t lj = j == 0 ? l[0] : j == 1 ? l[1] : j == 2 ? l[2] : l[3];
   return ((uint64_t)hj << 32) | lj;
 }
-RT_DEV double gen_log01(const Stream& s, uint32_t slot, double) { return rt_log((double)(word_at(s, slot) >> 11) * 0x1.0p-53); }
+RT_DEV double gen_log01(const Stream& s, uint32_t slot, double) {
+  const uint64_t w = word_at(s, slot);
+  return rt_log(u01_of((uint32_t)(w >> 32), (uint32_t)w, 0.0));
+}
 // Only the high word of the draw is generated: U moves by less than 2^-32, ln(U) by less than 2^-32 / U in absolute terms, far
 // below the resolution of a float path length, and the second Philox block per medium crossing is saved.
 RT_DEV float gen_log01(const Stream& s, uint32_t slot, float) {

@@ -31,6 +31,20 @@ template <int KIND> __global__ __launch_bounds__(256) void k(uint32_t* out, uint
       if constexpr (KIND == 9) d[i] = __builtin_sqrt(d[i]) + 1.0;
       if constexpr (KIND == 10) a[i] = __builtin_amdgcn_ds_bpermute((int)(a[i] & 252), (int)a[i]) + 1;
       if constexpr (KIND == 11) f[i] = __builtin_amdgcn_sqrtf(f[i]) + 1.0f;
+      if constexpr (KIND == 12) d[i] = (double)a[i] + d[i];
+      if constexpr (KIND == 13) d[i] = __builtin_ldexp(d[i], (int)(a[i] & 1u));
+      if constexpr (KIND == 14) { uint64_t x = (((uint64_t)a[i] << 31) | (uint64_t)(uint32_t)it) >> 11; a[i] = (uint32_t)x ^ (uint32_t)(x >> 32); }
+      if constexpr (KIND == 15) d[i] = (double)((((uint64_t)a[i]) << 20) | (uint64_t)(uint32_t)it) + d[i];
+      if constexpr (KIND == 16) d[i] = d[i] > 1.5 ? d[i] - 0.5 : d[i] + 0.25;
+      if constexpr (KIND == 17) d[i] = __builtin_fmax(d[i], 1.0001) + 0.001;
+      if constexpr (KIND == 18) d[i] = d[i] + 1.0001;
+      if constexpr (KIND == 19) d[i] = d[i] * 1.0001;
+      if constexpr (KIND == 20) a[i] = (a[i] & 1u) ? a[i] + 3u : a[i] ^ 5u;
+      if constexpr (KIND == 21) f[i] = (float)a[i] + f[i];
+      if constexpr (KIND == 22) a[i] += (uint32_t)__builtin_amdgcn_readlane((int)a[i], 3);
+      if constexpr (KIND == 23) f[i] = f[i] > 1.5f ? f[i] - 0.5f : f[i] + 0.25f;
+      if constexpr (KIND == 24) { float lo = 1.0f, hi = 2.0f; a[i] += (__builtin_amdgcn_fmed3f(f[i], lo, hi) == f[i]) ? 1u : 0u; f[i] += 0.001f; }
+      if constexpr (KIND == 25) { a[i] += ((d[i] >= 1.0) & (d[i] <= 2.0)) ? 1u : 0u; d[i] += 0.001; }
     }
   }
   uint32_t r = 0;
@@ -72,6 +86,20 @@ int main() {
   run<5>("1.0/x f64 + add", 12, d_out);
   run<9>("sqrt f64 + add", 12, d_out);
   run<10>("ds_bpermute + add", 2, d_out);
+  run<18>("v_add_f64", 1, d_out);
+  run<19>("v_mul_f64", 1, d_out);
+  run<12>("v_cvt_f64_u32 + add_f64", 2, d_out);
+  run<13>("v_ldexp_f64", 1, d_out);
+  run<14>("u64 shift/or + xor", 4, d_out);
+  run<15>("u64 -> f64 + add_f64", 6, d_out);
+  run<16>("f64: cmp + 2 arith + 2 cndmask", 5, d_out);
+  run<17>("v_max_f64 + add_f64", 2, d_out);
+  run<25>("f64: 2 cmp + and + addc, add_f64", 5, d_out);
+  run<20>("u32: and/cmp + add + xor + cndmask", 5, d_out);
+  run<21>("v_cvt_f32_u32 + add_f32", 2, d_out);
+  run<22>("v_readlane + add", 2, d_out);
+  run<23>("f32: cmp + 2 arith + cndmask", 4, d_out);
+  run<24>("f32: med3 + cmp + addc, add_f32", 4, d_out);
   CHECK(hipFree(d_out));
   return 0;
 }
