@@ -101,7 +101,9 @@ template <class R> RT_DEV void add_radiance(R* accum, uint32_t pixel, V3<R> c) {
     }                                                                      \
   } while (0)
 #define RT_STAMP_ATTACH(stream) do { (stream).stamp_acc = stamp_acc; (stream).stamp_t = &stamp_t; } while (0)
+#define RT_STAMP_COUNT(k, n) do { stamp_acc[k] += (unsigned long long)(n); } while (0)
 #else
+#define RT_STAMP_COUNT(k, n) do {} while (0)
 #define RT_STAMP_ATTACH(stream) do {} while (0)
 #define RT_STAMP_INIT() do {} while (0)
 #define RT_STAMP(k) do {} while (0)
@@ -476,6 +478,8 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
   bool any = false;
   Rec<R> rec;
   LaneBoxTest<R> box(Ray<R>{});
+  RT_STAMP_INIT();  // diagnostic build: cycles of [0] restart blocks, [1] box steps, [2] leaf steps; lanes taking part in [3] box steps,
+                    // [5] leaf steps, [7] restarts, and the number of [4] box steps, [6] leaf steps (restarts: [7] / lanes per restart)
   for (;;) {
     const unsigned long long idle = __ballot(i < 0);
     if ((uint32_t)__popcll(idle) >= kRestartLanes || idle == ~0ull) {
@@ -517,6 +521,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
       }
       const bool start = i < 0 && active && resume == 0u;
       n_rays += (unsigned long long)__popcll(__ballot(start));
+      RT_STAMP_COUNT(7, __popcll(__ballot(i < 0)));
       if (start) {
         box = LaneBoxTest<R>(st.ray);
         i = sc.root_link;
@@ -527,12 +532,15 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
       }
       if (__ballot(i >= 0 || resume != 0u) == 0ull) break;  // no walk in progress, no draw unfinished, no path left to start
     }
+    RT_STAMP(0);
 #pragma unroll 1
     for (int turn = 0; turn < kTurnsPerCheck; ++turn) {
 #pragma unroll 1
       for (int k = 0; k < kBoxStepsPerTurn; ++k) {
         const bool at_box = i >= 0 && !(lk.hit & LEAF_FLAG);
         if (__ballot(at_box) == 0ull) break;
+        RT_STAMP_COUNT(3, __popcll(__ballot(at_box)));
+        RT_STAMP_COUNT(4, 1);
         if (at_box) {
           i = box.hit(lk, st.ray, (R)0.001, closest) ? (int)lk.hit : lk.miss;
           if (i >= 0) lk = sv.link(i);
@@ -540,17 +548,22 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
       }
       // Leaves are tested when enough lanes stand on one (or no lane has a box to test): the leaf code is several times longer than
       // a box step, and run for the one or two lanes that happen to have arrived it would cost as much as for a full wave.
+      RT_STAMP(1);
       const bool at_leaf = i >= 0 && (lk.hit & LEAF_FLAG);
       const unsigned long long leaf_lanes = __ballot(at_leaf);
       if ((uint32_t)__popcll(leaf_lanes) < kLeafLanes && __ballot(i >= 0 && !(lk.hit & LEAF_FLAG)) != 0ull) continue;
+      RT_STAMP_COUNT(5, __popcll(leaf_lanes));
+      RT_STAMP_COUNT(6, 1);
       if (at_leaf) {
         Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
         if (leaf_hit<R, C, 0>(sv, lk.hit, st.ray, (R)0.001, closest, rec, media, st.org)) { closest = rec.t; any = true; }
         i = lk.miss;
         if (i >= 0) lk = sv.link(i);
       }
+      RT_STAMP(2);
     }
   }
+  RT_STAMP_FLUSH(ray_count);
   if (lane == 0u && n_rays != 0ull) atomicAdd(ray_count, n_rays);
 }
 

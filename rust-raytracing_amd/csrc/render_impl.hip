@@ -297,6 +297,12 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
       for (size_t w = 16; w + 8 <= kRayCountWords; w += 8)
         for (int k = 0; k < 8; ++k) st[k] += (double)all[w + k];
       for (int k = 0; k < 8; ++k) tot += st[k];
+      if (im.preset >= PRESET_BALLS_LDS) {  // the presets that run k_paths_stepwise (the table of the persistent kernel is printed as well; ignore it there)
+        const double cyc = st[0] + st[1] + st[2];
+        fprintf(stderr, "[stamps] stepwise: wave cycles restart %.1f%% box steps %.1f%% leaf steps %.1f%%; per ray: %.1f box steps of %.1f lanes, %.2f leaf steps of %.1f lanes, "
+                "restarts of %.1f idle lanes; %.0f cycles per 64 rays\n", 100 * st[0] / cyc, 100 * st[1] / cyc, 100 * st[2] / cyc,
+                st[3] / (double)rays, st[3] / st[4], st[5] / (double)rays, st[5] / st[6], 0.0, cyc / ((double)rays / 64.0));
+      }
       fprintf(stderr, "[stamps] persistent, wave cycles by phase (0 refill, 1 primary rays + trace rest, 2 scatter, 3 walk setup, 4 leaf loop, 5 finalize, 6 close ended paths, 7 Philox):");
       for (int k = 0; k < 8; ++k) fprintf(stderr, " [%d] %.1f%%", k, 100.0 * st[k] / tot);
       fprintf(stderr, "  %.0f cycles per wave iteration of %.1f rays\n", tot / ((double)rays / 64.0) , 64.0);
