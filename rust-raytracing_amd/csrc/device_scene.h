@@ -34,6 +34,12 @@ template <class R> struct alignas(16) DLink {  // 32 B (float) / 64 B (double)
   R bmax[3];
   int32_t miss;  // next entry when the box is missed / after a leaf was tested; LINK_END terminates
 };
+// The tree is stored with single-precision boxes in BOTH precisions: the double-precision image rounds its boxes outward to
+// floats, the double-precision walk converts them back (exactly) and tests them in double.  A box only decides which leaves get
+// tested; rounding it outward can add leaves to that set, never remove one (subtraction and multiplication round monotonically,
+// so the slab distances of the larger box bracket those of the exact one), and a leaf the reference's own boxes would have kept a
+// ray away from cannot be hit by that ray.  Half the bytes per tree entry for the walks that live on memory.
+using BoxLink = DLink<float>;
 
 // tags equal the RT_SHAPE_* / RT_MAT_* / RT_TEX_* / RT_OBJ_* values of rtamd.h
 enum { SH_SPHERE = 0, SH_MOVING = 1, SH_RECT_XY = 2, SH_RECT_XZ = 3, SH_RECT_YZ = 4, SH_BOX = 5 };
@@ -218,8 +224,8 @@ RT_DEV uint32_t load_uniform_u32(const uint32_t* p) {
 // (global memory, scalar loads) and per lane otherwise; materials, textures and Perlin tables are always gathered per lane
 // and sit in LDS unless only the top links fit there.
 template <class R, class C> struct SceneView {
-  const DLink<R>* links;
-  const DLink<R>* top;  // WALK_LANE_LDS_TOP: LDS copy of the first n_top links
+  const BoxLink* links;
+  const BoxLink* top;  // WALK_LANE_LDS_TOP: LDS copy of the first n_top links
   uint32_t n_top;
   uint32_t n_links;
   const DShape<R>* shapes;
@@ -236,7 +242,7 @@ template <class R, class C> struct SceneView {
   const DPerlin<R>* perlins;
   const DImage* images;
 
-  RT_DEV DLink<R> link(int i) const {
+  RT_DEV BoxLink link(int i) const {
     if constexpr (C::walk == WALK_LANE_LDS_TOP) {
       // the LDS copy is read through an LDS-typed pointer: a pointer that may be either LDS or global would turn every link
       // fetch of the walk into a flat load
@@ -267,7 +273,7 @@ RT_DEV void stage_to_lds(void* lds, const void* g, uint32_t bytes) {
 template <class R, class C> inline uint32_t lds_bytes_for(const BlobLayout& lay, uint32_t lds_links) {
   if (C::walk == WALK_UNIFORM) return lay.total_bytes;
   if (C::walk == WALK_LANE_LDS_ALL) return lay.total_bytes;
-  return lds_links * (uint32_t)sizeof(DLink<R>);
+  return lds_links * (uint32_t)sizeof(BoxLink);
 }
 
 template <class R, class C> RT_DEV SceneView<R, C> make_view(const DeviceScene<R>& sc, uint8_t* lds) {
@@ -289,13 +295,13 @@ template <class R, class C> RT_DEV SceneView<R, C> make_view(const DeviceScene<R
     shade = lds;
     lane = lds;
   } else {
-    stage_to_lds(lds, g + sc.lay.links_off, sc.lds_links * (uint32_t)sizeof(DLink<R>));
-    v.top = reinterpret_cast<const DLink<R>*>(lds);
+    stage_to_lds(lds, g + sc.lay.links_off, sc.lds_links * (uint32_t)sizeof(BoxLink));
+    v.top = reinterpret_cast<const BoxLink*>(lds);
     v.n_top = sc.lds_links;
   }
   __syncthreads();
   v.n_links = sc.lay.n_links;
-  v.links = reinterpret_cast<const DLink<R>*>(geom + sc.lay.links_off);
+  v.links = reinterpret_cast<const BoxLink*>(geom + sc.lay.links_off);
   v.shapes = reinterpret_cast<const DShape<R>*>(geom + sc.lay.shapes_off);
   v.objects = reinterpret_cast<const DObject<R>*>(geom + sc.lay.objects_off);
   v.shapes_lane = reinterpret_cast<const DShape<R>*>(lane + sc.lay.shapes_off);

@@ -350,10 +350,31 @@ RT_DEV bool leaf_hit(const SceneView<R, C>& sv, uint32_t leaf_word, const Ray<R>
 // the origin is far from zero compared with the box), interval logic by min/max, which agrees with the reference's form except
 // for rays lying exactly in a slab plane.
 template <class R> struct LaneBoxTest;
+// Double: the reciprocals are the IEEE quotients 1/d (the refined hardware estimate returns exactly those).  When all three are
+// finite and non-zero - every ray of a render - no product 0 * inf can occur, the reference's "swap if 1/d < 0" is the smaller /
+// larger of the two plane distances (an inverted box never reaches the device as such: see build_image), its three early outs
+// `t_max <= t_min` are one comparison at the end (t_min only grows, t_max only shrinks), and its compare-and-keep updates are
+// max / min: the same answer for a third fewer instructions.  A ray with a zero direction component takes src/aabb.rs:30-46 as
+// written, NaNs included.
 template <> struct LaneBoxTest<double> {
   V3<double> inv;
-  RT_DEV explicit LaneBoxTest(const Ray<double>& ray) : inv(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z) {}
-  RT_DEV bool hit(const DLink<double>& b, const Ray<double>& ray, double t_min, double t_max) const { return aabb_hit(b, ray, inv, t_min, t_max); }
+  bool plain;
+  RT_DEV explicit LaneBoxTest(const Ray<double>& ray) : inv(rcp_refined(ray.d.x), rcp_refined(ray.d.y), rcp_refined(ray.d.z)) {
+    plain = __builtin_isfinite(inv.x) & __builtin_isfinite(inv.y) & __builtin_isfinite(inv.z) & (inv.x != 0.0) & (inv.y != 0.0) & (inv.z != 0.0);
+  }
+  RT_DEV bool hit(const BoxLink& f, const Ray<double>& ray, double t_min, double t_max) const {
+    DLink<double> b;  // the stored box, widened to double (exact)
+    for (int k = 0; k < 3; ++k) { b.bmin[k] = (double)f.bmin[k]; b.bmax[k] = (double)f.bmax[k]; }
+    if (plain) {
+      const double x0 = (b.bmin[0] - ray.o.x) * inv.x, x1 = (b.bmax[0] - ray.o.x) * inv.x;
+      const double y0 = (b.bmin[1] - ray.o.y) * inv.y, y1 = (b.bmax[1] - ray.o.y) * inv.y;
+      const double z0 = (b.bmin[2] - ray.o.z) * inv.z, z1 = (b.bmax[2] - ray.o.z) * inv.z;
+      const double tn = rt_max(rt_max(rt_min(x0, x1), rt_min(y0, y1)), rt_max(rt_min(z0, z1), t_min));
+      const double tf = rt_min(rt_min(rt_max(x0, x1), rt_max(y0, y1)), rt_min(rt_max(z0, z1), t_max));
+      return tn < tf;
+    }
+    return aabb_hit(b, ray, inv, t_min, t_max);
+  }
 };
 template <> struct LaneBoxTest<float> {
   V3<float> inv;
@@ -377,7 +398,7 @@ RT_DEV bool traverse_lane(const SceneView<R, C>& sv, int start, const Ray<R>& ra
   bool any = false;
   int i = start;
   while (i >= 0) {
-    DLink<R> lk = sv.link(i);
+    BoxLink lk = sv.link(i);
     // Box entries first, until every lane of the wave stands on a leaf (or has left the tree): the leaf code below is then
     // entered by the lanes together instead of once per lane that happens to reach a leaf.
     while (!(lk.hit & LEAF_FLAG)) {

@@ -473,7 +473,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
   PathState<R> st;
   // walk state of the lane's current ray
   int i = LINK_END;     // entry to look at next; LINK_END = no walk in progress
-  DLink<R> lk{};        // entry i
+  BoxLink lk{};         // entry i
   R closest = Lim<R>::inf();
   bool any = false;
   Rec<R> rec;

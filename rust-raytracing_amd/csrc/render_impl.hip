@@ -1,5 +1,6 @@
 // Host-side render loop and test entry points for both arithmetic types.  The kernels themselves are reached through
 // the per-preset launcher tables of kernel_table.h.
+#include <limits>
 #include "context.h"
 #include "kernel_table.h"
 
@@ -42,7 +43,7 @@ template <> inline float round_up<float>(double x) {
 // Byte offsets of the blob's sections from the counts in `lay` (every section 16-byte aligned).
 template <class R> void layout_sections(BlobLayout& lay) {
   uint32_t off = 0;
-  lay.links_off = off; off = align16(off + lay.n_links * (uint32_t)sizeof(DLink<R>));
+  lay.links_off = off; off = align16(off + lay.n_links * (uint32_t)sizeof(BoxLink));
   lay.shapes_off = off; off = align16(off + lay.n_objects * (uint32_t)sizeof(DShape<R>));
   lay.objects_off = off; off = align16(off + lay.n_objects * (uint32_t)sizeof(DObject<R>));
   lay.materials_off = off; off = align16(off + lay.n_materials * (uint32_t)sizeof(DMaterial<R>));
@@ -133,9 +134,15 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
     for (int k = 0; k < 3; ++k)
       for (const FlatRect& r : frects[k]) *fr++ = r;
   }
-  auto* L = reinterpret_cast<DLink<R>*>(blob.data() + lay.links_off);
+  auto* L = reinterpret_cast<BoxLink*>(blob.data() + lay.links_off);  // single-precision boxes in both images (see BoxLink)
   for (size_t i = 0; i < links.size(); ++i) {
-    for (int k = 0; k < 3; ++k) { L[i].bmin[k] = round_down<R>(links[i].bmin[k]); L[i].bmax[k] = round_up<R>(links[i].bmax[k]); }
+    for (int k = 0; k < 3; ++k) { L[i].bmin[k] = round_down<float>(links[i].bmin[k]); L[i].bmax[k] = round_up<float>(links[i].bmax[k]); }
+    // A box that is inverted along some axis (the node of a lone sphere of negative radius, src/sphere.rs:75-81) fails the
+    // reference's test for every ray (src/aabb.rs:38-45: t_max <= t_min on that axis).  It is stored as the point at +infinity,
+    // which fails both forms of the test the kernels use - the reference's as written and the min/max form, which would
+    // otherwise read an inverted box as the ordinary one.
+    if (!(links[i].hit & LEAF_FLAG) && (links[i].bmin[0] > links[i].bmax[0] || links[i].bmin[1] > links[i].bmax[1] || links[i].bmin[2] > links[i].bmax[2]))
+      for (int k = 0; k < 3; ++k) L[i].bmin[k] = L[i].bmax[k] = std::numeric_limits<float>::infinity();
     L[i].hit = links[i].hit;
     L[i].miss = links[i].miss;
     // the double-precision walk looks at an object's flags only when its leaf is not marked simple; a re-centred sphere's
@@ -202,7 +209,7 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
   d.root_link = root_link;
   uint32_t top_bytes = kLdsTopMax;
   if (const char* e = getenv("RTAMD_TOP_LDS_BYTES")) top_bytes = (uint32_t)std::max(0, atoi(e));  // measurement switch
-  d.lds_links = (preset == PRESET_ALL_TOP || preset == PRESET_BALLS_TOP || preset == PRESET_FLATALL_TOP) ? std::min<uint32_t>(lay.n_links, top_bytes / (uint32_t)sizeof(DLink<R>)) : 0u;
+  d.lds_links = (preset == PRESET_ALL_TOP || preset == PRESET_BALLS_TOP || preset == PRESET_FLATALL_TOP) ? std::min<uint32_t>(lay.n_links, top_bytes / (uint32_t)sizeof(BoxLink)) : 0u;
   im.lds_bytes = im.table.lds_bytes(lay, d.lds_links);
   auto v3 = [](const double* p) { return V3<R>((R)p[0], (R)p[1], (R)p[2]); };
   d.camera.origin = v3(s.camera.origin); d.camera.lower_left_corner = v3(s.camera.lower_left_corner);
