@@ -254,6 +254,9 @@ constexpr uint32_t kPathGrab = 2048;
 #define RT_BLOCKS_PER_RESTART 3
 #endif
 constexpr uint32_t kBlocksPerTurn = 2, kBlocksPerRestart = RT_BLOCKS_PER_RESTART;
+#ifndef RT_NESTED_WAVES_F64
+#define RT_NESTED_WAVES_F64 3  // double precision, final-scene: 1.24 / 1.45 / 1.39 Grays/s at 2 / 3 / 4 waves per SIMD (fewer spills against fewer waves to hide the walk's loads)
+#endif
 #ifndef RT_NESTED_WAVES
 #define RT_NESTED_WAVES 4
 #endif
@@ -318,7 +321,7 @@ template <class R> struct PathFeeder {
 // CHUNKED: see FrameParams::chunk.  Carrying a chunk's sum costs three registers and a dozen instructions a turn (5-15 % on
 // frames that do not need it), so the launcher picks this variant only for frames made of short, cheap, bright paths.
 template <class R, class C, bool FIXED_GRAB, bool CHUNKED = false>
-__global__ __launch_bounds__(256, C::has(F_NESTED) ? RT_NESTED_WAVES : (C::has(F_NOISE) && sizeof(R) == 4 ? RT_NOISE_WAVES : (sizeof(R) == 8 ? RT_SMALL_WAVES_F64 : 1))) void k_paths_persistent(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
+__global__ __launch_bounds__(256, C::has(F_NESTED) ? (sizeof(R) == 8 ? RT_NESTED_WAVES_F64 : RT_NESTED_WAVES) : (C::has(F_NOISE) && sizeof(R) == 4 ? RT_NOISE_WAVES : (sizeof(R) == 8 ? RT_SMALL_WAVES_F64 : 1))) void k_paths_persistent(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
                                                           unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
   extern __shared__ __align__(16) uint8_t lds[];
   const SceneView<R, C> sv = make_view<R, C>(sc, lds);
