@@ -180,7 +180,7 @@ using CfgBallsLds = Cfg<P_BALLS, WALK_LANE_LDS_ALL>;
 using CfgBallsTop = Cfg<P_BALLS, WALK_LANE_LDS_TOP>;
 enum {
   PRESET_BOXES = 0, PRESET_SMOKE = 1, PRESET_SPHERES = 2, PRESET_ALL_LDS = 3, PRESET_ALL_TOP = 4, PRESET_BALLS_LDS = 5, PRESET_BALLS_TOP = 6,
-  PRESET_FLATALL_LDS = 7, PRESET_FLATALL_TOP = 8,  // single precision only
+  PRESET_FLATALL_LDS = 7, PRESET_FLATALL_TOP = 8,  // images whose nested trees were dissolved (the library's own tree)
   PRESET_COUNT = 9
 };
 

@@ -14,8 +14,8 @@ template <class R> KernelTable<R> table_for(int preset) {
     case PRESET_ALL_LDS: return kernel_table<R, PRESET_ALL_LDS>();
     case PRESET_BALLS_LDS: return kernel_table<R, PRESET_BALLS_LDS>();
     case PRESET_BALLS_TOP: return kernel_table<R, PRESET_BALLS_TOP>();
-    case PRESET_FLATALL_LDS: if constexpr (sizeof(R) == sizeof(float)) return kernel_table<float, PRESET_FLATALL_LDS>(); else break;
-    case PRESET_FLATALL_TOP: if constexpr (sizeof(R) == sizeof(float)) return kernel_table<float, PRESET_FLATALL_TOP>(); else break;
+    case PRESET_FLATALL_LDS: return kernel_table<R, PRESET_FLATALL_LDS>();
+    case PRESET_FLATALL_TOP: return kernel_table<R, PRESET_FLATALL_TOP>();
     default: break;
   }
   return kernel_table<R, PRESET_ALL_TOP>();

@@ -460,11 +460,11 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     rc_sd = build_image<double>(c, *s, links, root, sub_root, preset, c->sd);
     if (rc_sd != RT_OK) err_sd = g_err;
   });
-  // RT_F64_OWN_TREE: the library's tree once more, in double (the presets without nested-walk code exist in single only)
+  // RT_F64_OWN_TREE: the library's tree once more, in double
   std::thread t_own([&] {
     if (!want_own64) return;
     if (hipSetDevice(device) != hipSuccess) { rc_own = RT_E_HIP; err_own = "hipSetDevice failed"; return; }
-    rc_own = build_image<double>(c, scene32, fast_links, fast_root, fast_sub_root, preset32 == PRESET_FLATALL_LDS ? PRESET_ALL_LDS : preset32, c->sd_own);
+    rc_own = build_image<double>(c, scene32, fast_links, fast_root, fast_sub_root, preset32, c->sd_own);
     if (rc_own != RT_OK) err_own = g_err;
   });
   rc = own_tree ? build_image<float>(c, scene32, fast_links, fast_root, fast_sub_root, preset32, c->sf)
