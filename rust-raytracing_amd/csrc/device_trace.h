@@ -242,6 +242,23 @@ template <class R, class C, int LEVEL>
 RT_DEV bool traverse_lane(const SceneView<R, C>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org,
                           uint32_t visit = 0u, Visits* tally = nullptr);
 
+// What RotateY::hit and Translate::hit do to the record of a hit found below them (src/hittable.rs:229-239, 146-148).
+template <class R> RT_DEV void record_to_world(const DObject<R>& ob, V3<R> local_d, V3<R> moved_d, Rec<R>& rec) {
+  if (ob.flags & OBJ_ROTATE_Y) {  // src/hittable.rs:229-239
+    V3<R> p = rec.p, n = rec.n;
+    p.x = ob.cos_theta * rec.p.x + ob.sin_theta * rec.p.z;
+    p.z = -ob.sin_theta * rec.p.x + ob.cos_theta * rec.p.z;
+    n.x = ob.cos_theta * rec.n.x + ob.sin_theta * rec.n.z;
+    n.z = -ob.sin_theta * rec.n.x + ob.cos_theta * rec.n.z;
+    rec.p = p;
+    rec.set_face_normal(local_d, n);  // object-space direction against a world-space normal, as the reference does
+  }
+  if (ob.flags & OBJ_TRANSLATE) {  // src/hittable.rs:146-148
+    rec.p = rec.p + V3<R>(ob.offset[0], ob.offset[1], ob.offset[2]);
+    rec.set_face_normal(moved_d, rec.n);
+  }
+}
+
 // [Translate(] [RotateY(] geometry [))] — the part of an object below an optional ConstantMedium.
 template <class R, class C, int LEVEL>
 RT_DEV bool boundary_hit(const SceneView<R, C>& sv, const DObject<R>& ob, int obj_index, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec,
@@ -270,19 +287,7 @@ RT_DEV bool boundary_hit(const SceneView<R, C>& sv, const DObject<R>& ob, int ob
   if (!nested) hit = shape_hit<R, C>(sv.shape(obj_index), obj_index, local, t_min, t_max, rec, org.leaf() == obj_index ? org.side() : -2);
   if (!hit) return false;
   if constexpr (C::has(F_XFORM)) {
-    if (ob.flags & OBJ_ROTATE_Y) {  // src/hittable.rs:229-239
-      V3<R> p = rec.p, n = rec.n;
-      p.x = ob.cos_theta * rec.p.x + ob.sin_theta * rec.p.z;
-      p.z = -ob.sin_theta * rec.p.x + ob.cos_theta * rec.p.z;
-      n.x = ob.cos_theta * rec.n.x + ob.sin_theta * rec.n.z;
-      n.z = -ob.sin_theta * rec.n.x + ob.cos_theta * rec.n.z;
-      rec.p = p;
-      rec.set_face_normal(local.d, n);  // object-space direction against a world-space normal, as the reference does
-    }
-    if (ob.flags & OBJ_TRANSLATE) {  // src/hittable.rs:146-148
-      rec.p = rec.p + V3<R>(ob.offset[0], ob.offset[1], ob.offset[2]);
-      rec.set_face_normal(moved.d, rec.n);
-    }
+    record_to_world(ob, local.d, moved.d, rec);
     if (ob.flags & OBJ_FRONT_CHAIN) {  // a re-centred sphere: front_face as RotateY's mixed-frame call would have left it (src/hittable.rs:236-239)
       const R dlx = ob.cos_theta * ray.d.x - ob.sin_theta * ray.d.z, dlz = ob.sin_theta * ray.d.x + ob.cos_theta * ray.d.z;
       rec.front = (dlx * rec.n.x + ray.d.y * rec.n.y + dlz * rec.n.z) < (R)0;
