@@ -7,6 +7,7 @@
 #include "accel_build.h"
 #include "context.h"
 
+#include <limits>
 #include <mutex>
 #include <thread>
 
@@ -67,7 +68,42 @@ struct LinkBuilder {
   std::vector<TmpLink> links;
   std::vector<uint8_t> node_seen;
   std::string err;
+  // splice[o] != 0: the nested tree held by object o is emitted in place of o's leaf, its boxes turned into world-space boxes
+  // around what the holder's RotateY / Translate make of them (see rt_upload_scene)
+  const std::vector<char>* splice = nullptr;
   explicit LinkBuilder(const rt_scene_desc& sc) : s(sc), node_seen((size_t)std::max(0, sc.n_nodes), 0) {}
+
+  // Axis-aligned box around a box of holder `h`'s frame taken to world space (src/hittable.rs:166-197 for the rotation, 127-138
+  // for the translation), with a margin that covers the rounding of these few operations many times over.
+  void to_world_box(int h, double mn[3], double mx[3]) const {
+    const rt_object& ob = s.objects[h];
+    double lo[3] = {mn[0], mn[1], mn[2]}, hi[3] = {mx[0], mx[1], mx[2]};
+    if (ob.flags & RT_OBJ_ROTATE_Y) {
+      const double inf = std::numeric_limits<double>::infinity();
+      double a[3] = {inf, inf, inf}, b[3] = {-inf, -inf, -inf};
+      for (int k = 0; k < 8; ++k) {
+        const double x = (k & 1) ? hi[0] : lo[0], y = (k & 2) ? hi[1] : lo[1], z = (k & 4) ? hi[2] : lo[2];
+        const double w[3] = {ob.cos_theta * x + ob.sin_theta * z, y, -ob.sin_theta * x + ob.cos_theta * z};
+        for (int q = 0; q < 3; ++q) { a[q] = std::min(a[q], w[q]); b[q] = std::max(b[q], w[q]); }
+      }
+      for (int q = 0; q < 3; ++q) { lo[q] = a[q]; hi[q] = b[q]; }
+    }
+    // A box that comes through unchanged, or moved by an offset that adds without rounding, stays exactly the box the reference
+    // tests: where two boxes of a nested tree share a face (the ground blocks of final-scene), whether the second one is still
+    // visited after a hit on that face hangs on an exact `t_max <= t_min`, and with it which of the two coincident sides is
+    // reported.  Only a rotated box, or a sum that had to round, gets a margin.
+    const bool rotated = (ob.flags & RT_OBJ_ROTATE_Y) != 0;
+    for (int q = 0; q < 3; ++q) {
+      double a = lo[q], b = hi[q];
+      bool exact = !rotated;
+      if (ob.flags & RT_OBJ_TRANSLATE) {
+        a = lo[q] + ob.offset[q]; b = hi[q] + ob.offset[q];
+        exact = exact && (a - ob.offset[q] == lo[q]) && (a - lo[q] == ob.offset[q]) && (b - ob.offset[q] == hi[q]) && (b - hi[q] == ob.offset[q]);
+      }
+      const double m = exact ? 0.0 : 1e-9 * std::max({1.0, std::fabs(a), std::fabs(b)});
+      mn[q] = a - m; mx[q] = b + m;
+    }
+  }
 
   bool simple(int obj) const { return (s.objects[obj].flags & 15u) == 0u; }
 
@@ -79,15 +115,17 @@ struct LinkBuilder {
     links.push_back(l);
     return (int)links.size() - 1;
   }
-  int child(int c, int next, int depth, int tree) {
-    if (c >= 0) return node(c, next, depth, tree);
+  int child(int c, int next, int depth, int tree, int holder = -1) {
+    if (c >= 0) return node(c, next, depth, tree, holder);
     int obj = ~c;
     if (obj < 0 || obj >= s.n_objects) { err = "BVH leaf references an object out of range"; return LINK_END; }
-    if (tree != 0 && (s.objects[obj].flags & RT_OBJ_SUB_BVH)) { err = "nested BVH inside a nested BVH is not supported"; return LINK_END; }
+    if ((tree != 0 || holder >= 0) && (s.objects[obj].flags & RT_OBJ_SUB_BVH)) { err = "nested BVH inside a nested BVH is not supported"; return LINK_END; }
+    if (splice && (*splice)[(size_t)obj]) return node(s.objects[obj].geom, next, depth, tree, obj);  // the nested tree in place of its holder
     return leaf(obj, next, depth, tree);
   }
   // Emits the subtree of `n`; returns the index of its first link.  `next` is where traversal continues afterwards.
-  int node(int n, int next, int depth, int tree) {
+  // `holder` >= 0: the subtree belongs to the nested tree of that object and is being spliced into the world's tree.
+  int node(int n, int next, int depth, int tree, int holder = -1) {
     if (!err.empty()) return LINK_END;
     if (n < 0 || n >= s.n_nodes) { err = "BVH node index out of range"; return LINK_END; }
     if (node_seen[n]) { err = "BVH node referenced twice (nodes must form trees)"; return LINK_END; }
@@ -101,15 +139,16 @@ struct LinkBuilder {
     // shape with t_max = its own t reproduces the first record, so it is dropped unless the object draws random numbers.
     bool twin = nd.left < 0 && nd.left == nd.right && !(s.objects[std::min(std::max(~nd.left, 0), s.n_objects - 1)].flags & RT_OBJ_MEDIUM);
     if (twin) {
-      left_first = child(nd.left, next, depth + 1, tree);
+      left_first = child(nd.left, next, depth + 1, tree, holder);
     } else {
-      right_first = child(nd.right, next, depth + 1, tree);
+      right_first = child(nd.right, next, depth + 1, tree, holder);
       // a medium in a one-object node: its second visit draws a random number of its own (src/constant_medium.rs:91)
       if (nd.left < 0 && nd.left == nd.right && right_first >= 0) links[(size_t)right_first].hit |= LEAF_SECOND;
-      left_first = child(nd.left, right_first, depth + 1, tree);
+      left_first = child(nd.left, right_first, depth + 1, tree, holder);
     }
     TmpLink& l = links[me];
     for (int k = 0; k < 3; ++k) { l.bmin[k] = nd.bmin[k]; l.bmax[k] = nd.bmax[k]; }
+    if (holder >= 0 && !(l.bmin[0] > l.bmax[0] || l.bmin[1] > l.bmax[1] || l.bmin[2] > l.bmax[2])) to_world_box(holder, l.bmin, l.bmax);
     l.hit = (uint32_t)left_first;
     l.miss = next;
     l.depth = depth; l.tree = tree;
@@ -420,6 +459,58 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     }
     if (has_nested && !nested_left && preset == PRESET_ALL_LDS) preset32 = PRESET_FLATALL_LDS;  // build_image demotes to _TOP when too large
   }
+  // Double precision, the caller's tree: a nested tree whose holder only translates / rotates it and whose objects are bare shapes
+  // is spliced into the world's tree in place of its holder - same entries in the same order, so the same leaf is tested at the
+  // same point of the walk with the same t_max.  Its objects take the holder's wrappers: Translate(RotateY(shape)) forms the
+  // same local ray and takes the record back with the same operations as Translate(RotateY(tree)) does around the shape's hit,
+  // bit for bit.  Its boxes become world-space boxes around the rotated and translated originals: larger, which can only add
+  // leaves to the ones a ray gets to test (see BoxLink).  The image then has no nested tree and runs the kernels without
+  // nested-walk code, whose lanes step through the tree instead of each finishing its own walk inside a turn (final-scene: 10
+  // of 64 lanes were active there).  RTAMD_KEEP_NESTED=1 turns this off as well.
+  std::vector<rt_object> objects64(s->objects, s->objects + s->n_objects);
+  std::vector<char> splice((size_t)s->n_objects, 0);
+  bool nested_left64 = false, spliced_any = false;
+  if (!uniform && has_nested) {
+    for (int i = 0; i < s->n_objects; ++i) {
+      const rt_object& holder = s->objects[i];
+      if (!(holder.flags & RT_OBJ_SUB_BVH)) continue;
+      std::vector<int> children;
+      for (int k = sub_root[(size_t)i]; k >= 0;) {
+        const TmpLink& l = lb.links[(size_t)k];
+        if (l.hit & LEAF_FLAG) { children.push_back((int)(l.hit & LEAF_INDEX_MASK)); k = l.miss; }
+        else k = (int)l.hit;
+      }
+      bool bare = !(holder.flags & RT_OBJ_MEDIUM) && !std::getenv("RTAMD_KEEP_NESTED");
+      for (int ch : children) bare = bare && s->objects[ch].flags == 0u;
+      if (!bare) { nested_left64 = true; continue; }
+      splice[(size_t)i] = 1;
+      spliced_any = true;
+      for (int ch : children) {
+        rt_object& o = objects64[(size_t)ch];
+        o.flags = holder.flags & (RT_OBJ_TRANSLATE | RT_OBJ_ROTATE_Y);
+        for (int k = 0; k < 3; ++k) o.offset[k] = holder.offset[k];
+        o.sin_theta = holder.sin_theta; o.cos_theta = holder.cos_theta;
+      }
+    }
+  }
+  rt_scene_desc scene64 = *s;
+  scene64.objects = objects64.data();
+  std::vector<TmpLink> links64;
+  int root64 = LINK_END;
+  std::vector<int> sub_root64((size_t)s->n_objects, LINK_END);
+  int preset64 = preset;
+  if (spliced_any) {
+    LinkBuilder lbs(scene64);
+    lbs.splice = &splice;
+    root64 = lbs.node(s->root_node, LINK_END, 0, 0);
+    int tree64 = 1;
+    for (int i = 0; i < s->n_objects && lbs.err.empty(); ++i)
+      if ((s->objects[i].flags & RT_OBJ_SUB_BVH) && !splice[(size_t)i]) sub_root64[(size_t)i] = lbs.node(s->objects[i].geom, LINK_END, 0, tree64++);
+    if (!lbs.err.empty()) return fail(RT_E_INVALID, "rt_upload_scene: " + lbs.err);
+    links64 = reorder(lbs.links, root64, sub_root64);
+    if (!nested_left64 && preset == PRESET_ALL_LDS) preset64 = PRESET_FLATALL_LDS;
+    mark("nested trees spliced (f64)");
+  }
   rt_scene_desc scene32 = *s;
   scene32.objects = objects32.data();
   scene32.shapes = shapes32.data();
@@ -457,7 +548,8 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   const int device = c->device;
   std::thread t_sd([&] {
     if (hipSetDevice(device) != hipSuccess) { rc_sd = RT_E_HIP; err_sd = "hipSetDevice failed"; return; }
-    rc_sd = build_image<double>(c, *s, links, root, sub_root, preset, c->sd);
+    rc_sd = spliced_any ? build_image<double>(c, scene64, links64, root64, sub_root64, preset64, c->sd)
+                        : build_image<double>(c, *s, links, root, sub_root, preset, c->sd);
     if (rc_sd != RT_OK) err_sd = g_err;
   });
   // RT_F64_OWN_TREE: the library's tree once more, in double
