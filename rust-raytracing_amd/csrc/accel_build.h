@@ -113,6 +113,7 @@ class FastTreeBuilder {
     return out;
   }
 
+ public:
   // Everything that decides what a ray sees of an object, by value (compared bit for bit).
   struct Signature {
     double v[28];
@@ -155,6 +156,14 @@ class FastTreeBuilder {
     }
     return g;  // 26 values at most; the rest stays zero
   }
+  // Objects that may stand in for an exact copy of themselves: bare or wrapped shapes, but no medium (it draws random numbers per
+  // visit), no nested tree, and no sphere of negative radius (what reaches it is decided by the boxes around each copy).
+  bool copy_eligible(int o) const {
+    const rt_object& ob = s_.objects[o];
+    return !(ob.flags & (RT_OBJ_MEDIUM | RT_OBJ_SUB_BVH)) && !has_guard(o);
+  }
+
+ private:
 
   // A sphere of negative radius (the hollow-glass trick, src/scenes.rs:235-239) reports an inverted box (src/sphere.rs:75-81),
   // which barely widens its parent's box in the reference's tree: there the sphere is only ever tested by rays that pass the box

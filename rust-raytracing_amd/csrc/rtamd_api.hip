@@ -10,6 +10,7 @@
 #include <limits>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 
 namespace rti {
 thread_local std::string g_err;
@@ -71,6 +72,8 @@ struct LinkBuilder {
   // splice[o] != 0: the nested tree held by object o is emitted in place of o's leaf, its boxes turned into world-space boxes
   // around what the holder's RotateY / Translate make of them (see rt_upload_scene)
   const std::vector<char>* splice = nullptr;
+  // skip[o] != 0: object o is an exact copy of an object the walk visits later; its leaf is left out (see rt_upload_scene)
+  const std::vector<char>* skip = nullptr;
   explicit LinkBuilder(const rt_scene_desc& sc) : s(sc), node_seen((size_t)std::max(0, sc.n_nodes), 0) {}
 
   // Axis-aligned box around a box of holder `h`'s frame taken to world space (src/hittable.rs:166-197 for the rotation, 127-138
@@ -121,6 +124,7 @@ struct LinkBuilder {
     if (obj < 0 || obj >= s.n_objects) { err = "BVH leaf references an object out of range"; return LINK_END; }
     if ((tree != 0 || holder >= 0) && (s.objects[obj].flags & RT_OBJ_SUB_BVH)) { err = "nested BVH inside a nested BVH is not supported"; return LINK_END; }
     if (splice && (*splice)[(size_t)obj]) return node(s.objects[obj].geom, next, depth, tree, obj);  // the nested tree in place of its holder
+    if (skip && (*skip)[(size_t)obj]) return next;  // no entry: whoever pointed here goes on with what follows
     return leaf(obj, next, depth, tree);
   }
   // Emits the subtree of `n`; returns the index of its first link.  `next` is where traversal continues afterwards.
@@ -149,6 +153,10 @@ struct LinkBuilder {
     TmpLink& l = links[me];
     for (int k = 0; k < 3; ++k) { l.bmin[k] = nd.bmin[k]; l.bmax[k] = nd.bmax[k]; }
     if (holder >= 0 && !(l.bmin[0] > l.bmax[0] || l.bmin[1] > l.bmax[1] || l.bmin[2] > l.bmax[2])) to_world_box(holder, l.bmin, l.bmax);
+    if (left_first < 0) {  // nothing left below this node (every leaf was an earlier copy) and nothing after it: a box no ray enters
+      for (int k = 0; k < 3; ++k) { l.bmin[k] = 1.0; l.bmax[k] = -1.0; }
+      left_first = me;
+    }
     l.hit = (uint32_t)left_first;
     l.miss = next;
     l.depth = depth; l.tree = tree;
@@ -493,23 +501,61 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
       }
     }
   }
+  // Exact copies (the `random` scene adds its three large spheres 22 times, src/scenes.rs:197-217): every copy returns the same
+  // distance, a tie the reference gives to the copy its walk tests last.  The earlier copies' leaves are left out of the list -
+  // 17 sphere tests per ray become 5 - and the answer is the one the reference gives.
+  std::vector<char> skip((size_t)s->n_objects, 0);
+  bool skipped_any = false;
+  // One thing does change: a hit that does not write (u, v) - a moving sphere, a medium - reports whatever an earlier accepted hit
+  // left in the reference's shared record, and with fewer accepted hits on the way that leftover can be another.  Only an image
+  // texture reads (u, v): with one on such an object the copies stay.
+  bool stale_uv_read = false;
+  for (int i = 0; i < s->n_objects; ++i) {
+    const rt_object& o = s->objects[i];
+    auto reads_uv = [&](int mat) {
+      if (mat < 0 || mat >= s->n_materials) return false;
+      const int tx = s->materials[mat].texture;
+      if (tx < 0 || tx >= s->n_textures) return false;
+      const rt_texture& t = s->textures[tx];
+      auto image = [&](int k) { return k >= 0 && k < s->n_textures && s->textures[k].tag == RT_TEX_IMAGE; };
+      return t.tag == RT_TEX_IMAGE || (t.tag == RT_TEX_CHECKER && (image(t.even) || image(t.odd)));
+    };
+    if (o.flags & RT_OBJ_MEDIUM) stale_uv_read = stale_uv_read || reads_uv(o.medium_material);
+    if (!(o.flags & RT_OBJ_SUB_BVH) && s->shapes[o.geom].tag == RT_SHAPE_MOVING_SPHERE) stale_uv_read = stale_uv_read || reads_uv(s->shapes[o.geom].material);
+  }
+  if (!uniform && !stale_uv_read && !std::getenv("RTAMD_KEEP_COPIES")) {
+    FastTreeBuilder sig(*s);
+    std::unordered_map<FastTreeBuilder::Signature, int, FastTreeBuilder::SignatureHash> last;
+    std::vector<int> order;
+    for (int k = root; k >= 0;) {
+      const TmpLink& l = lb.links[(size_t)k];
+      if (l.hit & LEAF_FLAG) { order.push_back((int)(l.hit & LEAF_INDEX_MASK)); k = l.miss; }
+      else k = (int)l.hit;
+    }
+    for (int o : order)
+      if (sig.copy_eligible(o)) last[sig.signature(o)] = o;
+    for (int o : order)
+      if (sig.copy_eligible(o) && last.find(sig.signature(o))->second != o) { skip[(size_t)o] = 1; skipped_any = true; }
+  }
   rt_scene_desc scene64 = *s;
   scene64.objects = objects64.data();
   std::vector<TmpLink> links64;
   int root64 = LINK_END;
   std::vector<int> sub_root64((size_t)s->n_objects, LINK_END);
   int preset64 = preset;
-  if (spliced_any) {
+  const bool relinked = spliced_any || skipped_any;
+  if (relinked) {
     LinkBuilder lbs(scene64);
     lbs.splice = &splice;
+    lbs.skip = &skip;
     root64 = lbs.node(s->root_node, LINK_END, 0, 0);
     int tree64 = 1;
     for (int i = 0; i < s->n_objects && lbs.err.empty(); ++i)
       if ((s->objects[i].flags & RT_OBJ_SUB_BVH) && !splice[(size_t)i]) sub_root64[(size_t)i] = lbs.node(s->objects[i].geom, LINK_END, 0, tree64++);
     if (!lbs.err.empty()) return fail(RT_E_INVALID, "rt_upload_scene: " + lbs.err);
     links64 = reorder(lbs.links, root64, sub_root64);
-    if (!nested_left64 && preset == PRESET_ALL_LDS) preset64 = PRESET_FLATALL_LDS;
-    mark("nested trees spliced (f64)");
+    if (has_nested && !nested_left64 && preset == PRESET_ALL_LDS) preset64 = PRESET_FLATALL_LDS;
+    mark("f64 list: nested trees spliced, copies left out");
   }
   rt_scene_desc scene32 = *s;
   scene32.objects = objects32.data();
@@ -548,7 +594,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   const int device = c->device;
   std::thread t_sd([&] {
     if (hipSetDevice(device) != hipSuccess) { rc_sd = RT_E_HIP; err_sd = "hipSetDevice failed"; return; }
-    rc_sd = spliced_any ? build_image<double>(c, scene64, links64, root64, sub_root64, preset64, c->sd)
+    rc_sd = relinked ? build_image<double>(c, scene64, links64, root64, sub_root64, preset64, c->sd)
                         : build_image<double>(c, *s, links, root, sub_root, preset, c->sd);
     if (rc_sd != RT_OK) err_sd = g_err;
   });

@@ -70,9 +70,15 @@ def test_first_hit_random_rays_f64(gpu, rtamd, oracle, earth_rgb, name):
     assert dist_err(rays, gh, oh, ok).max() < 1e-11 and t_err.max() < 1e-8, (dist_err(rays, gh, oh, ok).max(), t_err.max())
     assert p_err.max() < 1e-11 and n_err.max() < 1e-9
     # (u, v) of a medium hit are whatever an earlier candidate left in the reference's shared record
-    # (src/constant_medium.rs never writes them; no texture of an Isotropic material reads them): not compared.
+    # (src/constant_medium.rs never writes them; no texture of an Isotropic material reads them): not compared.  The same goes for a
+    # moving sphere (src/moving_sphere.rs:44-72 writes no u, v): the leftover depends on which hits were accepted on the way, and
+    # the library leaves exact copies of an object out of the walk (`random` holds its large spheres 22 times), which keeps the hit
+    # but not the leftover; only an image texture would read it, and with one on a moving sphere the copies stay in.
     iso = np.array([int(m["tag"]) == 4 for m in hs.materials()])
-    surf = ok & ~iso[np.clip(oh["material"], 0, None)]
+    objs, shapes = hs.objects(), hs.shapes()
+    moving_ids = {(int(o["obj_id"]), int(o["sub_id"])) for o in objs if not (int(o["flags"]) & 8) and int(shapes[o["geom"]]["tag"]) == 1}
+    on_moving = np.array([(int(a), int(b)) in moving_ids for a, b in zip(oh["obj"], oh["sub"])]) if moving_ids else np.zeros(rays.size, dtype=bool)
+    surf = ok & ~iso[np.clip(oh["material"], 0, None)] & ~on_moving
     uv_err = np.abs(np.stack([gh["u"], gh["v"]], 1)[surf] - np.stack([oh["u"], oh["v"]], 1)[surf]).max()
     assert uv_err < 1e-9, uv_err
 
