@@ -162,6 +162,28 @@ class FastTreeBuilder {
     const rt_object& ob = s_.objects[o];
     return !(ob.flags & (RT_OBJ_MEDIUM | RT_OBJ_SUB_BVH)) && !has_guard(o);
   }
+  // out[o] = 1 for every object of `order` (objects in the order a walk visits them) that is an exact copy of an object coming
+  // later in it.  `eligible(o)` says which objects take part.  Open-addressing table of (hash, last object with that signature).
+  template <class Pred> std::vector<char> earlier_copies(const std::vector<int>& order, Pred eligible) const {
+    size_t cap = 16;
+    while (cap < 2 * order.size()) cap <<= 1;
+    struct Slot { uint64_t hash; int obj; };
+    std::vector<Slot> table(cap, Slot{0, -1});
+    std::vector<int> slot_of((size_t)s_.n_objects, -1);
+    for (int o : order) {
+      if (!eligible(o)) continue;
+      const Signature g = signature(o);
+      const uint64_t h = (uint64_t)SignatureHash()(g);
+      size_t k = (size_t)h & (cap - 1);
+      while (table[k].obj >= 0 && !(table[k].hash == h && signature(table[k].obj) == g)) k = (k + 1) & (cap - 1);
+      table[k] = Slot{h, o};  // a later copy takes the place of an earlier one
+      slot_of[(size_t)o] = (int)k;
+    }
+    std::vector<char> out((size_t)s_.n_objects, 0);
+    for (int o : order)
+      if (eligible(o) && table[(size_t)slot_of[(size_t)o]].obj != o) out[(size_t)o] = 1;
+    return out;
+  }
 
  private:
 
@@ -372,7 +394,6 @@ class FastTreeBuilder {
 
   void emit_tree(const std::vector<int>& objs_in_order, int tree, std::vector<TmpLink>& out, Box3d& root_box) {
     // copies: keep the last visited one
-    // open-addressing table of (hash, last object with that signature)
     const bool timing = std::getenv("RTAMD_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) {
@@ -381,27 +402,15 @@ class FastTreeBuilder {
       std::fprintf(stderr, "  own tree %d: %-22s %.3f s\n", tree, what, std::chrono::duration<double>(now - t_last).count());
       t_last = now;
     };
-    size_t cap = 16;
-    while (cap < 2 * objs_in_order.size()) cap <<= 1;
-    struct Slot { uint64_t hash; int obj; };
-    std::vector<Slot> table(cap, Slot{0, -1});
-    std::vector<int> slot_of((size_t)s_.n_objects, -1);
+    const std::vector<char> earlier = earlier_copies(objs_in_order, [&](int o) { return !(s_.objects[o].flags & (RT_OBJ_MEDIUM | RT_OBJ_SUB_BVH)); });
     std::vector<int> keep;
-    for (int o : objs_in_order) {
-      const rt_object& ob = s_.objects[o];
-      if (ob.flags & (RT_OBJ_MEDIUM | RT_OBJ_SUB_BVH)) { keep.push_back(o); continue; }
-      const Signature g = signature(o);
-      const uint64_t h = (uint64_t)SignatureHash()(g);
-      size_t k = (size_t)h & (cap - 1);
-      while (table[k].obj >= 0 && !(table[k].hash == h && signature(table[k].obj) == g)) k = (k + 1) & (cap - 1);
-      table[k] = Slot{h, o};  // a later copy takes the place of an earlier one
-      slot_of[(size_t)o] = (int)k;
-    }
+    for (int o : objs_in_order)
+      if (s_.objects[o].flags & (RT_OBJ_MEDIUM | RT_OBJ_SUB_BVH)) keep.push_back(o);
     mark("copies");
     for (int o : objs_in_order) {
       const rt_object& ob = s_.objects[o];
       if (ob.flags & (RT_OBJ_MEDIUM | RT_OBJ_SUB_BVH)) continue;
-      if (table[(size_t)slot_of[(size_t)o]].obj != o) continue;
+      if (earlier[(size_t)o]) continue;
       if (has_guard(o)) {
         // alone in a one-object node, the inverted box IS the node's box, and the reference's box test (src/aabb.rs:30-46) fails
         // for every ray: the sphere is never tested there, so it is not part of this tree either

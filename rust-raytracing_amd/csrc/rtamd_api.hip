@@ -525,17 +525,15 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   }
   if (!uniform && !stale_uv_read && !std::getenv("RTAMD_KEEP_COPIES")) {
     FastTreeBuilder sig(*s);
-    std::unordered_map<FastTreeBuilder::Signature, int, FastTreeBuilder::SignatureHash> last;
     std::vector<int> order;
     for (int k = root; k >= 0;) {
       const TmpLink& l = lb.links[(size_t)k];
       if (l.hit & LEAF_FLAG) { order.push_back((int)(l.hit & LEAF_INDEX_MASK)); k = l.miss; }
       else k = (int)l.hit;
     }
-    for (int o : order)
-      if (sig.copy_eligible(o)) last[sig.signature(o)] = o;
-    for (int o : order)
-      if (sig.copy_eligible(o) && last.find(sig.signature(o))->second != o) { skip[(size_t)o] = 1; skipped_any = true; }
+    skip = sig.earlier_copies(order, [&](int o) { return sig.copy_eligible(o); });
+    for (char f : skip) skipped_any = skipped_any || f != 0;
+    mark("f64 list: copies found");
   }
   rt_scene_desc scene64 = *s;
   scene64.objects = objects64.data();
