@@ -309,6 +309,29 @@ def test_f64_on_the_librarys_own_tree(gpu, rtamd, oracle, earth_rgb, name, mega_
     assert vb["u"].mean() < va["u"].mean()
 
 
+@pytest.mark.parametrize("name,switch", [("random", "RTAMD_KEEP_COPIES"), ("final-scene", "RTAMD_KEEP_NESTED")])
+def test_f64_list_variants_agree(gpu, rtamd, oracle, earth_rgb, name, switch, monkeypatch):
+    """The f64 image of the caller's tree leaves exact copies out of the walk and splices bare nested trees into the world's tree.
+    With either choice switched off the kernels walk the tree literally (all 22 copies; the nested-tree kernels): ids, t, p and
+    the normal must be the same bit for bit - only the leftover (u, v) of moving spheres may differ (see the first test)."""
+    hs, _ = make_pair(rtamd, oracle, name, earth=earth_rgb)
+    rng = np.random.default_rng(2468)
+    lo, hi = SCENE_BOXES[name]
+    rays = random_rays(rng, 100_000, lo, hi)
+    gpu.upload(hs)
+    a = gpu.trace_batch(rays, precision=rtamd.F64, seed=3)
+    monkeypatch.setenv(switch, "1")
+    gpu.upload(hs)
+    b = gpu.trace_batch(rays, precision=rtamd.F64, seed=3)
+    monkeypatch.delenv(switch)
+    gpu.upload(hs)
+    for f in ID_FIELDS + ("t", "p", "n"):
+        assert np.array_equal(a[f], b[f]), (name, switch, f)
+    sa = gpu.render_accum(None, 0, 1, precision=rtamd.F64, seed=3)
+    assert sa["scene_in_lds"] in (5, 6, 7, 8), sa["scene_in_lds"]  # by default neither scene takes a nested-tree preset
+
+
+
 def test_medium_in_a_one_object_node(gpu, rtamd, oracle, earth_rgb):
     """With axis seed 13 the reference's tree of final-scene puts the fog-filled glass ball (object 6 of the world list, a
     ConstantMedium) alone into a one-object node, which holds it twice (src/bvh.rs:38) and calls it twice (src/bvh.rs:114-116).
