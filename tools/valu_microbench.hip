@@ -44,6 +44,8 @@ template <int KIND> __global__ __launch_bounds__(256) void k(uint32_t* out, uint
       if constexpr (KIND == 22) a[i] += (uint32_t)__builtin_amdgcn_readlane((int)a[i], 3);
       if constexpr (KIND == 23) f[i] = f[i] > 1.5f ? f[i] - 0.5f : f[i] + 0.25f;
       if constexpr (KIND == 24) { float lo = 1.0f, hi = 2.0f; a[i] += (__builtin_amdgcn_fmed3f(f[i], lo, hi) == f[i]) ? 1u : 0u; f[i] += 0.001f; }
+      if constexpr (KIND == 26) a[i] = __umulhi(a[i], 0xD2511F53u) + (uint32_t)it;
+      if constexpr (KIND == 27) { uint32_t hi = __umulhi(a[i], 0xD2511F53u), lo = a[i] * 0xD2511F53u; a[i] = hi ^ lo ^ (uint32_t)it; }
       if constexpr (KIND == 25) { a[i] += ((d[i] >= 1.0) & (d[i] <= 2.0)) ? 1u : 0u; d[i] += 0.001; }
     }
   }
@@ -86,6 +88,8 @@ int main() {
   run<5>("1.0/x f64 + add", 12, d_out);
   run<9>("sqrt f64 + add", 12, d_out);
   run<10>("ds_bpermute + add", 2, d_out);
+  run<26>("v_mul_hi_u32 + add", 2, d_out);
+  run<27>("mul_hi + mul_lo + 2 xor", 4, d_out);
   run<18>("v_add_f64", 1, d_out);
   run<19>("v_mul_f64", 1, d_out);
   run<12>("v_cvt_f64_u32 + add_f64", 2, d_out);
