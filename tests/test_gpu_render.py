@@ -263,7 +263,7 @@ def test_many_perlin_tables_leave_the_small_scene_preset(gpu, rtamd, oracle):
 
 
 # Converged images: the HIP path against the CPU oracle as two INDEPENDENT Monte-Carlo estimates (different seeds), at a frame and
-# sample count the oracle can afford.  Stated tolerance (also in DESIGN.md): per-channel mean of linear radiance (clamped to [0,1]
+# sample count the oracle can afford.  Stated tolerance: per-channel mean of linear radiance (clamped to [0,1]
 # per pixel, as color_to_rgb clamps) within 1.5 % relative, RMSE of 8x8 block means within 3 % of the image mean.
 CONVERGED = {  # width, aspect, spp
     "random": (320, 16 / 9, 128), "two-spheres": (320, 16 / 9, 128), "two-perlin-spheres": (320, 16 / 9, 128), "earth": (320, 16 / 9, 128),
