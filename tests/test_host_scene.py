@@ -71,6 +71,20 @@ def test_bvh_is_seeded_and_reference_ordered(rtamd):
     assert cs.desc.n_nodes == 7 and cs.desc.n_objects == 8
 
 
+def test_threaded_bvh_build_equals_the_serial_one(rtamd, oracle, monkeypatch):
+    """The host builds the reference's tree on several threads (the axis sequence is drawn up front, a node's index follows from
+    object counts alone): the node array must be byte for byte what one thread produces, and the root box the oracle's own
+    recursive build arrives at.  19 600 objects: above the size at which subtrees are handed to threads."""
+    monkeypatch.setenv("OMP_NUM_THREADS", "1")
+    one = rtamd.Scene("mega-spheres", mega_grid=70).nodes().tobytes()
+    monkeypatch.setenv("OMP_NUM_THREADS", "8")
+    hs = rtamd.Scene("mega-spheres", mega_grid=70)
+    assert hs.nodes().tobytes() == one
+    os_ = oracle.OracleScene("mega-spheres", mega_grid=70)
+    root = hs.nodes()[hs.desc.root_node]
+    assert np.array_equal(np.concatenate([root["bmin"], root["bmax"]]), os_.root_box())
+
+
 def test_cornell_geometry_constants(rtamd):
     # src/scenes.rs:341-381
     s = rtamd.Scene("cornell-box")
