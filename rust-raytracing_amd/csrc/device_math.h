@@ -30,6 +30,12 @@ RT_DEV float rt_min(float a, float b) { return __builtin_fminf(a, b); }
 RT_DEV double rt_min(double a, double b) { return __builtin_fmin(a, b); }
 RT_DEV float rt_max(float a, float b) { return __builtin_fmaxf(a, b); }
 RT_DEV double rt_max(double a, double b) { return __builtin_fmax(a, b); }
+// min / max of values that are known not to be signalling NaNs (products and sums the hardware has already made canonical): the
+// plain instruction, without the canonicalising self-maximum the compiler puts in front of fmin / fmax when it cannot tell.
+RT_DEV double min_plain(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RT_DEV double max_plain(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RT_DEV float min_plain(float a, float b) { return __builtin_fminf(a, b); }
+RT_DEV float max_plain(float a, float b) { return __builtin_fmaxf(a, b); }
 RT_DEV float rt_sin(float x) { return sinf(x); }
 RT_DEV double rt_sin(double x) { return sin(x); }
 RT_DEV float rt_log(float x) { return logf(x); }

@@ -94,7 +94,7 @@ RT_DEV bool shape_t(const DShape<R>& s, const Ray<R>& ray, const RayInv<R>& ri, 
 // Ray in the space of the geometry below [Translate(] [RotateY(] (src/hittable.rs:141,214-223).
 template <class R> RT_DEV void to_local(const DObject<R>& ob, const Ray<R>& ray, Ray<R>& moved, Ray<R>& local) {
   moved = ray;
-  if (ob.flags & OBJ_TRANSLATE) moved.o = ray.o - V3<R>(ob.offset[0], ob.offset[1], ob.offset[2]);
+  moved.o = ray.o - V3<R>(ob.offset[0], ob.offset[1], ob.offset[2]);  // the offset of an object without Translate is stored as zero: x - 0 = x
   local = moved;
   if (ob.flags & OBJ_ROTATE_Y) {
     local.o.x = ob.cos_theta * moved.o.x - ob.sin_theta * moved.o.z;
@@ -316,11 +316,11 @@ RT_DEV bool box_slab_t(const DShape<R>& s, const Ray<R>& ray, const RayRcp<R>& r
   const R x0 = (s.p[0] - ray.o.x) * ri.inv.x, x1 = (s.p[3] - ray.o.x) * ri.inv.x;
   const R y0 = (s.p[1] - ray.o.y) * ri.inv.y, y1 = (s.p[4] - ray.o.y) * ri.inv.y;
   const R z0 = (s.p[2] - ray.o.z) * ri.inv.z, z1 = (s.p[5] - ray.o.z) * ri.inv.z;
-  const R nx = rt_min(x0, x1), fx = rt_max(x0, x1);
-  const R ny = rt_min(y0, y1), fy = rt_max(y0, y1);
-  const R nz = rt_min(z0, z1), fz = rt_max(z0, z1);
-  const R tn = rt_max(rt_max(nx, ny), nz);
-  const R tf = rt_min(rt_min(fx, fy), fz);
+  const R nx = min_plain(x0, x1), fx = max_plain(x0, x1);
+  const R ny = min_plain(y0, y1), fy = max_plain(y0, y1);
+  const R nz = min_plain(z0, z1), fz = max_plain(z0, z1);
+  const R tn = max_plain(max_plain(nx, ny), nz);
+  const R tf = min_plain(min_plain(fx, fy), fz);
   // sides: 0 z=hi, 1 z=lo, 2 y=hi, 3 y=lo, 4 x=hi, 5 x=lo; the near plane of an axis is lo when the ray moves up that axis
   const int px = ray.d.x > (R)0 ? 1 : 0, py = ray.d.y > (R)0 ? 1 : 0, pz = ray.d.z > (R)0 ? 1 : 0;
   const int near_side = nx == tn ? 4 + px : (ny == tn ? 2 + py : pz);
@@ -338,8 +338,8 @@ template <class R> RT_DEV bool box_slab_span(const DShape<R>& s, const Ray<R>& r
   const R x0 = (s.p[0] - ray.o.x) * ri.inv.x, x1 = (s.p[3] - ray.o.x) * ri.inv.x;
   const R y0 = (s.p[1] - ray.o.y) * ri.inv.y, y1 = (s.p[4] - ray.o.y) * ri.inv.y;
   const R z0 = (s.p[2] - ray.o.z) * ri.inv.z, z1 = (s.p[5] - ray.o.z) * ri.inv.z;
-  tn = rt_max(rt_max(rt_min(x0, x1), rt_min(y0, y1)), rt_min(z0, z1));
-  tf = rt_min(rt_min(rt_max(x0, x1), rt_max(y0, y1)), rt_max(z0, z1));
+  tn = max_plain(max_plain(min_plain(x0, x1), min_plain(y0, y1)), min_plain(z0, z1));
+  tf = min_plain(min_plain(max_plain(x0, x1), max_plain(y0, y1)), max_plain(z0, z1));
   return tn <= tf;
 }
 

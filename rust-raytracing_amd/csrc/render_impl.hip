@@ -164,7 +164,7 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
     O[i].flags = o.flags;
     O[i].sub_root = sub_root_of_object[i];
     O[i].medium_material = o.medium_material;
-    for (int k = 0; k < 3; ++k) O[i].offset[k] = (R)o.offset[k];
+    for (int k = 0; k < 3; ++k) O[i].offset[k] = (o.flags & RT_OBJ_TRANSLATE) ? (R)o.offset[k] : (R)0;  // subtracted unconditionally on the device
     O[i].sin_theta = (R)o.sin_theta; O[i].cos_theta = (R)o.cos_theta; O[i].neg_inv_density = (R)o.neg_inv_density;
   }
   auto* M = reinterpret_cast<DMaterial<R>*>(blob.data() + lay.materials_off);
