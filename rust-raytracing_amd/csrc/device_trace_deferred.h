@@ -44,7 +44,9 @@ template <> struct RayInv<float> {
 
 // src/aarect.rs:88-97: distance to the plane, range test, in-plane bounds (closed).  Written without early exits: the six
 // comparisons are the reference's own (negated, so a NaN passes them as it does there) and their conjunction decides.
-template <class R, int AXIS, class RI>
+// KEEP: t_out is left alone on a miss (callers that pass their running t_max as t_out); otherwise it receives the plane distance
+// whatever the outcome and the caller selects once.
+template <class R, int AXIS, class RI, bool KEEP = true>
 RT_DEV bool rect_t(R a0, R a1, R b0, R b1, R k, const Ray<R>& ray, const RI& ri, R t_min, R t_max, R& t_out) {
   constexpr int A = (AXIS == 0) ? 1 : 0;
   constexpr int B = (AXIS == 2) ? 1 : 2;
@@ -54,7 +56,7 @@ RT_DEV bool rect_t(R a0, R a1, R b0, R b1, R k, const Ray<R>& ray, const RI& ri,
   const R a = o[A] + t * d[A];
   const R b = o[B] + t * d[B];
   const bool ok = !(t < t_min) & !(t > t_max) & !(a < a0) & !(a > a1) & !(b < b0) & !(b > b1);
-  if (ok) t_out = t;
+  if constexpr (KEEP) { if (ok) t_out = t; } else t_out = t;
   return ok;
 }
 
@@ -304,7 +306,7 @@ RT_DEV bool rect_fast(float a0, float a1, float b0, float b1, float k, const Ray
 template <int AXIS>
 RT_DEV bool rect_fast(double a0, double a1, double b0, double b1, double k, const Ray<double>& ray, const RayRcp<double>& ri, double t_min,
                       double t_max, double& t_out) {
-  return rect_t<double, AXIS>(a0, a1, b0, b1, k, ray, ri, t_min, t_max, t_out);
+  return rect_t<double, AXIS, RayRcp<double>, false>(a0, a1, b0, b1, k, ray, ri, t_min, t_max, t_out);
 }
 
 // The six sides of a box (src/box_struct.rs:22-71) as three slabs: the ray meets the surface where it enters (largest of the
