@@ -275,9 +275,18 @@ template <class S> RT_DEV V3<float> random_in_unit_sphere(const S& s, float) {
 }
 // Double build: the high fields alone decide all but a sliver of candidates (the low fields move a coordinate by less than
 // 2^-20, the squared length by less than 5.8e-6), so the low words are formed once, for the candidate that passes that test.
-template <class S> RT_DEV V3<double> random_in_unit_sphere(const S& s, double) {
-  uint32_t c = 2u * s.first_block();
+// The screening runs in single precision: the 21-bit fields are exact there, and the rounding of the squared length (below 4e-7)
+// is covered by the margin.
+RT_DEV bool unit_ball_screen(uint32_t w0, uint32_t w1) { return length_squared(point_of<float>(w0, w1, 0u, 0u, 0u)) < 1.0f + 8e-6f; }
+RT_DEV V3<double> unit_ball_point(uint32_t w0, uint32_t w1) {
+  uint32_t l[3];
+  low3(w0, w1, l);
+  return point_of<double>(w0, w1, l[0], l[1], l[2]);
+}
+// The plain loop, from candidate c on.
+template <class S> RT_DEV V3<double> unit_ball_loop(const S& s, uint32_t c) {
   uint32_t h[4] = {0u, 0u, 0u, 0u};
+  if (c & 1u) s.hi(c >> 1, h);
   for (;;) {
     uint32_t w0, w1;
     for (;; ++c) {
@@ -287,16 +296,44 @@ template <class S> RT_DEV V3<double> random_in_unit_sphere(const S& s, double) {
       }
       w0 = (c & 1u) ? h[2] : h[0];
       w1 = (c & 1u) ? h[3] : h[1];
-      // this screening runs in single precision: the 21-bit fields are exact there, and the rounding of the squared length
-      // (below 4e-7) is covered by the margin
-      if (length_squared(point_of<float>(w0, w1, 0u, 0u, 0u)) < 1.0f + 8e-6f) break;
+      if (unit_ball_screen(w0, w1)) break;
     }
-    uint32_t l[3];
-    low3(w0, w1, l);
-    V3<double> p = point_of<double>(w0, w1, l[0], l[1], l[2]);
+    const V3<double> p = unit_ball_point(w0, w1);
     if (length_squared(p) < 1.0) return p;
     ++c;
   }
+}
+template <class S> RT_DEV V3<double> random_in_unit_sphere(const S& s, double) { return unit_ball_loop(s, 2u * s.first_block()); }
+// On a primed stream (the path kernels): the block that is already there gives two candidates, screened side by side in every
+// lane; the lanes that found none (a quarter) evaluate the next block and screen its two; then the candidate in double - three
+// dozen instructions - is formed ONCE for all lanes.  As a loop over candidates that part runs again in every turn in which some
+// lane passes the screening, three or four times per draw.  What is left over (no candidate in two blocks when the turn allows
+// more, or a candidate inside the sliver between the screening's bound and the ball) goes through the plain loop.
+RT_DEV V3<double> random_in_unit_sphere(const PrimedStream& s, double) {
+  const uint32_t b0 = s.b0;
+  const bool p0 = unit_ball_screen(s.h0[0], s.h0[1]), p1 = unit_ball_screen(s.h0[2], s.h0[3]);
+  uint32_t w0 = p0 ? s.h0[0] : s.h0[2], w1 = p0 ? s.h0[1] : s.h0[3];
+  uint32_t c = 2u * b0 + (p0 ? 0u : 1u);
+  bool have = p0 | p1;
+  bool rest = false;  // go on in the plain loop from candidate c
+  if (!have) {
+    c = 2u * (b0 + 1u);
+    if (s.out_of_turn(b0 + 1u)) return V3<double>(0.0, 0.0, 1.0);  // not a draw: the caller sees s.resume and calls again
+    uint32_t h[4];
+    s.Stream::hi(b0 + 1u, h);
+    const bool p2 = unit_ball_screen(h[0], h[1]), p3 = unit_ball_screen(h[2], h[3]);
+    w0 = p2 ? h[0] : h[2]; w1 = p2 ? h[1] : h[3];
+    c += p2 ? 0u : 1u;
+    have = p2 | p3;
+    if (!have) { c = 2u * (b0 + 2u); rest = true; }
+  }
+  V3<double> p(0.0, 0.0, 1.0);
+  if (have) {
+    p = unit_ball_point(w0, w1);
+    if (!(length_squared(p) < 1.0)) { c += 1u; rest = true; }
+  }
+  if (rest) p = unit_ball_loop(s, c);
+  return p;
 }
 template <class R, class S> RT_DEV V3<R> random_in_unit_sphere(const S& s) { return random_in_unit_sphere(s, (R)0); }
 // src/vec3.rs:90-92.  Single precision scales by the hardware reciprocal square root (1 ulp) instead of sqrt then divide.
