@@ -187,14 +187,18 @@ RT_DEV Ray<R> primary_ray(const DCamera<R>& cam, uint32_t W, uint32_t H, uint32_
   R v_rand = jitter.u01(1);
   R s = jitter_coord<RELAXED>(i, u_rand, W - 1u);
   R t = jitter_coord<RELAXED>(j, v_rand, H - 1u);
-  // a pinhole camera (lens_radius == 0) multiplies the disk sample by zero; draws are addressed, so skipping it moves nothing else
-  V3<R> rd((R)0, (R)0, (R)0);
-  if (cam.lens_radius != (R)0) rd = cam.lens_radius * random_in_unit_disk<R>(rng);
-  V3<R> offset = rd.x * cam.u + rd.y * cam.v;
+  // a pinhole camera (lens_radius == 0, the same in every lane) multiplies the disk sample by zero: the offset is a zero vector,
+  // x - 0 = x and x + 0 = x, so neither the sample nor the offset is formed; draws are addressed, so skipping them moves nothing else
   Ray<R> ray;
-  ray.d = cam.lower_left_corner + s * cam.horizontal + t * cam.vertical - cam.origin - offset;
+  ray.d = cam.lower_left_corner + s * cam.horizontal + t * cam.vertical - cam.origin;
+  ray.o = cam.origin;
+  if (cam.lens_radius != (R)0) {
+    const V3<R> rd = cam.lens_radius * random_in_unit_disk<R>(rng);
+    const V3<R> offset = rd.x * cam.u + rd.y * cam.v;
+    ray.d = ray.d - offset;
+    ray.o = cam.origin + offset;
+  }
   ray.time = jitter.range(2, cam.t_open, cam.t_close);
-  ray.o = cam.origin + offset;
   return ray;
 }
 template <class R, bool RELAXED = false>
