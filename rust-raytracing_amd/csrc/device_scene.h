@@ -99,8 +99,8 @@ struct BlobLayout {
   uint32_t links_off, shapes_off, objects_off, materials_off, textures_off, perlins_off, flat_off, total_bytes;
   uint32_t n_links, n_objects, n_materials, n_textures, n_perlins;
   // Small scenes (flat_mode != 0): the tree's leaves as lists.  Single precision: plain rectangles, grouped by their constant
-  // axis (n_frect[0] YZ, [1] XZ, [2] XY), as FlatRect records at frect_off; every other leaf as its leaf word, in visiting order,
-  // at flat_off (n_flat of them).  Double precision: every leaf as its leaf word, in visiting order (no FlatRect records).
+  // axis (n_frect[0] YZ, [1] XZ, [2] XY), as FlatRect records at frect_off; every other leaf as a FlatLeaf record, in visiting
+  // order, at flat_off (n_flat of them).  Double precision: every leaf as a FlatLeaf record, in visiting order (no FlatRect records).
   uint32_t n_flat, flat_mode, frect_off, n_frect[3];
   uint32_t faces_off;  // FlatFace records, six per object (flat_mode only)
 };
@@ -120,6 +120,17 @@ template <class R> struct DeviceScene {
 struct alignas(16) FlatRect {  // a plain rectangle ready for the test: plane coordinate, in-plane bounds, object index
   float k, a0, a1, b0, b1;
   int32_t obj, pad0, pad1;
+};
+
+// One leaf of a small scene as the flat walk reads it: the leaf word, the shape and the holder's wrappers in one record, stored
+// in visiting order, so that a step of the walk is one scalar fetch whose address depends on no earlier fetch (the leaf word, then
+// the shape it names, then the object record would be three fetches in a row).
+template <class R> struct alignas(16) FlatLeaf {  // 80 B (float) / 144 B (double)
+  uint32_t word;
+  int32_t tag, obj_id;
+  uint32_t flags;
+  R p[10];
+  R offset[3], sin_theta, cos_theta, neg_inv_density;
 };
 
 // One planar side of a rectangle or box, as the record of a hit needs it (small scenes, flat walk): slot 6 * object + side,
@@ -230,7 +241,7 @@ template <class R, class C> struct SceneView {
   uint32_t n_links;
   const DShape<R>* shapes;
   const DObject<R>* objects;
-  const uint32_t* flat;            // leaf words in visiting order (global memory, scalar loads), n_flat of them
+  const FlatLeaf<R>* flat;         // leaves in visiting order (global memory, scalar loads), n_flat of them
   uint32_t n_flat;
   const FlatRect* frect;           // plain rectangles by axis (global memory, scalar loads)
   uint32_t n_frect[3];
@@ -311,7 +322,7 @@ template <class R, class C> RT_DEV SceneView<R, C> make_view(const DeviceScene<R
   v.textures = reinterpret_cast<const DTexture<R>*>(shade + (sc.lay.textures_off - shade_sub));
   v.perlins = reinterpret_cast<const DPerlin<R>*>(shade + (sc.lay.perlins_off - shade_sub));
   v.images = sc.images;
-  v.flat = reinterpret_cast<const uint32_t*>(g + sc.lay.flat_off);
+  v.flat = reinterpret_cast<const FlatLeaf<R>*>(g + sc.lay.flat_off);
   v.n_flat = sc.lay.n_flat;
   v.frect = reinterpret_cast<const FlatRect*>(g + sc.lay.frect_off);
   for (int k = 0; k < 3; ++k) v.n_frect[k] = sc.lay.n_frect[k];

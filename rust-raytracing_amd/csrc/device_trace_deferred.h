@@ -385,10 +385,23 @@ RT_DEV bool traverse_flat(const SceneView<R, C>& sv, int start, const Ray<R>& ra
         closest = ok ? t : closest; best_leaf = ok ? r.obj : best_leaf; best_side = ok ? -1 : best_side;
       }
     }
+#ifdef RT_FLAT_PREFETCH
+    FlatLeaf<R> fl_next;
+    if (sv.n_flat != 0u) fl_next = load_uniform(sv.flat);
+#endif
     for (uint32_t k = 0; k < sv.n_flat; ++k) {
-      const uint32_t word = load_uniform_u32(sv.flat + k);
+#ifdef RT_FLAT_PREFETCH
+      const FlatLeaf<R> fl = fl_next;
+      fl_next = load_uniform(sv.flat + (k + 1u < sv.n_flat ? k + 1u : k));  // the next leaf's record is fetched while this one is tested
+#else
+      const FlatLeaf<R> fl = load_uniform(sv.flat + k);
+#endif
+      const uint32_t word = fl.word;
       const int obj = (int)(word & LEAF_INDEX_MASK);
-      const DShape<R> s = sv.shape(obj);
+      DShape<R> s;
+      s.tag = fl.tag; s.obj_id = fl.obj_id; s.material = 0; s.sub_id = 0;
+#pragma unroll
+      for (int q = 0; q < 10; ++q) s.p[q] = fl.p[q];
       const bool self = org_leaf == obj;
       R t = (R)0;
       int side = -1;
@@ -398,7 +411,10 @@ RT_DEV bool traverse_flat(const SceneView<R, C>& sv, int start, const Ray<R>& ra
       RayRcp<R> rl = ri;
       if constexpr (C::has(F_XFORM) || C::has(F_MEDIUM)) {
         if (!plain) {
-          const DObject<R> ob = sv.object(obj);
+          DObject<R> ob;
+          ob.flags = fl.flags; ob.sub_root = -1; ob.medium_material = -1;
+          ob.offset[0] = fl.offset[0]; ob.offset[1] = fl.offset[1]; ob.offset[2] = fl.offset[2];
+          ob.sin_theta = fl.sin_theta; ob.cos_theta = fl.cos_theta; ob.neg_inv_density = fl.neg_inv_density;
           bool medium = false;
           if constexpr (C::has(F_MEDIUM)) medium = (ob.flags & OBJ_MEDIUM) != 0u;
           if (medium) {

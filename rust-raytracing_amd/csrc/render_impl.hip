@@ -49,7 +49,7 @@ template <class R> void layout_sections(BlobLayout& lay) {
   lay.materials_off = off; off = align16(off + lay.n_materials * (uint32_t)sizeof(DMaterial<R>));
   lay.textures_off = off; off = align16(off + lay.n_textures * (uint32_t)sizeof(DTexture<R>));
   lay.perlins_off = off; off = align16(off + lay.n_perlins * (uint32_t)sizeof(DPerlin<R>));
-  lay.flat_off = off; off = align16(off + (uint32_t)(kFlatMaxLeaves * sizeof(uint32_t)));
+  lay.flat_off = off; off = align16(off + (uint32_t)(std::max(1u, lay.n_flat) * sizeof(FlatLeaf<R>)));
   lay.frect_off = off; off = align16(off + (uint32_t)(kFlatMaxLeaves * sizeof(FlatRect)));
   lay.faces_off = off;
   if (lay.flat_mode) off = align16(off + (uint32_t)(6u * lay.n_objects * sizeof(FlatFace<R>)));
@@ -128,7 +128,21 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
       }
     }
   }
-  if (!others.empty()) memcpy(blob.data() + lay.flat_off, others.data(), others.size() * sizeof(uint32_t));
+  {
+    FlatLeaf<R>* fl = reinterpret_cast<FlatLeaf<R>*>(blob.data() + lay.flat_off);
+    for (uint32_t word : others) {
+      const rt_object& o = s.objects[word & LEAF_INDEX_MASK];
+      FlatLeaf<R>& f = *fl++;
+      f.word = word; f.tag = -1; f.obj_id = o.obj_id; f.flags = o.flags;
+      if (!(o.flags & RT_OBJ_SUB_BVH)) {
+        const rt_shape& sh = s.shapes[o.geom];
+        f.tag = sh.tag;
+        for (int k = 0; k < 9; ++k) f.p[k] = (R)sh.p[k];
+      }
+      for (int k = 0; k < 3; ++k) f.offset[k] = (o.flags & RT_OBJ_TRANSLATE) ? (R)o.offset[k] : (R)0;  // subtracted unconditionally on the device
+      f.sin_theta = (R)o.sin_theta; f.cos_theta = (R)o.cos_theta; f.neg_inv_density = (R)o.neg_inv_density;
+    }
+  }
   {
     FlatRect* fr = reinterpret_cast<FlatRect*>(blob.data() + lay.frect_off);
     for (int k = 0; k < 3; ++k)
