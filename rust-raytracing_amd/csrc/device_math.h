@@ -47,12 +47,13 @@ RT_DEV double rt_atan2(double y, double x) { return atan2(y, x); }
 
 // 1/x in double precision from the hardware estimate (about 26 bits) and two Newton steps: on gfx950 the result is the IEEE
 // quotient 1.0/x for every finite non-zero x tried (2^20 random arguments, tools/rcp_probe.hip), at half the instructions of the
-// division sequence.  Zero and infinite arguments keep the estimate's own answer (inf / 0), as the division would give.
+// division sequence.  Zero, infinite and NaN arguments, for which the Newton steps make NaN, get the division's answer (inf / 0 /
+// NaN) from the instruction the division sequence itself ends with; it passes every other quotient through unchanged.
 RT_DEV double rcp_refined(double x) {
   const double r0 = __builtin_amdgcn_rcp(x);
   const double r1 = __builtin_fma(__builtin_fma(-x, r0, 1.0), r0, r0);
   const double r2 = __builtin_fma(__builtin_fma(-x, r1, 1.0), r1, r1);
-  return __builtin_isfinite(r0) && r0 != 0.0 ? r2 : r0;
+  return __builtin_amdgcn_div_fixup(r2, x, 1.0);
 }
 // 1/sqrt(x), hardware estimate and two Newton steps: within 2 ulp (same probe).
 RT_DEV double rsq_refined(double x) {

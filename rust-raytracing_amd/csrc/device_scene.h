@@ -89,6 +89,12 @@ template <class R> struct DCamera {  // src/camera.rs:6-17
   V3<R> origin, lower_left_corner, horizontal, vertical, u, v;
   R lens_radius, t_open, t_close;
 };
+// The camera as a record of the scene blob (origin, lower_left_corner, horizontal, vertical, u, v, lens_radius, t_open, t_close
+// in that order): the path kernels fetch it where a primary ray is made instead of holding 21 kernel arguments in scalar
+// registers for the whole launch.
+template <class R> struct alignas(16) CameraRecord {
+  R f[sizeof(R) == 8 ? 22 : 24];
+};
 template <class R> struct DBackground {  // src/color.rs:35-39
   int32_t kind;
   V3<R> c0, c1;
@@ -103,6 +109,7 @@ struct BlobLayout {
   // order, at flat_off (n_flat of them).  Double precision: every leaf as a FlatLeaf record, in visiting order (no FlatRect records).
   uint32_t n_flat, flat_mode, frect_off, n_frect[3];
   uint32_t faces_off;  // FlatFace records, six per object (flat_mode only)
+  uint32_t camera_off; // one CameraRecord
 };
 
 template <class R> struct DeviceScene {
@@ -226,11 +233,6 @@ template <class T> RT_DEV T load_lds(const T* p) {
   return u.t;
 }
 
-RT_DEV uint32_t load_uniform_u32(const uint32_t* p) {
-  typedef const __attribute__((address_space(4))) uint32_t* const_ptr;
-  return *(const_ptr)(uintptr_t)p;
-}
-
 // What the hit / shade routines read.  `links`, `shapes`, `objects` are read with wave-uniform indices in WALK_UNIFORM
 // (global memory, scalar loads) and per lane otherwise; materials, textures and Perlin tables are always gathered per lane
 // and sit in LDS unless only the top links fit there.
@@ -252,7 +254,17 @@ template <class R, class C> struct SceneView {
   const DTexture<R>* textures;
   const DPerlin<R>* perlins;
   const DImage* images;
+  const CameraRecord<R>* camera_rec;  // global memory, scalar loads
 
+  RT_DEV DCamera<R> camera() const {
+    const CameraRecord<R> r = load_uniform(camera_rec);
+    DCamera<R> c;
+    c.origin = V3<R>(r.f[0], r.f[1], r.f[2]); c.lower_left_corner = V3<R>(r.f[3], r.f[4], r.f[5]);
+    c.horizontal = V3<R>(r.f[6], r.f[7], r.f[8]); c.vertical = V3<R>(r.f[9], r.f[10], r.f[11]);
+    c.u = V3<R>(r.f[12], r.f[13], r.f[14]); c.v = V3<R>(r.f[15], r.f[16], r.f[17]);
+    c.lens_radius = r.f[18]; c.t_open = r.f[19]; c.t_close = r.f[20];
+    return c;
+  }
   RT_DEV BoxLink link(int i) const {
     if constexpr (C::walk == WALK_LANE_LDS_TOP) {
       // the LDS copy is read through an LDS-typed pointer: a pointer that may be either LDS or global would turn every link
@@ -324,6 +336,7 @@ template <class R, class C> RT_DEV SceneView<R, C> make_view(const DeviceScene<R
   v.images = sc.images;
   v.flat = reinterpret_cast<const FlatLeaf<R>*>(g + sc.lay.flat_off);
   v.n_flat = sc.lay.n_flat;
+  v.camera_rec = reinterpret_cast<const CameraRecord<R>*>(g + sc.lay.camera_off);
   v.frect = reinterpret_cast<const FlatRect*>(g + sc.lay.frect_off);
   for (int k = 0; k < 3; ++k) v.n_frect[k] = sc.lay.n_frect[k];
   return v;

@@ -385,17 +385,8 @@ RT_DEV bool traverse_flat(const SceneView<R, C>& sv, int start, const Ray<R>& ra
         closest = ok ? t : closest; best_leaf = ok ? r.obj : best_leaf; best_side = ok ? -1 : best_side;
       }
     }
-#ifdef RT_FLAT_PREFETCH
-    FlatLeaf<R> fl_next;
-    if (sv.n_flat != 0u) fl_next = load_uniform(sv.flat);
-#endif
     for (uint32_t k = 0; k < sv.n_flat; ++k) {
-#ifdef RT_FLAT_PREFETCH
-      const FlatLeaf<R> fl = fl_next;
-      fl_next = load_uniform(sv.flat + (k + 1u < sv.n_flat ? k + 1u : k));  // the next leaf's record is fetched while this one is tested
-#else
       const FlatLeaf<R> fl = load_uniform(sv.flat + k);
-#endif
       const uint32_t word = fl.word;
       const int obj = (int)(word & LEAF_INDEX_MASK);
       DShape<R> s;

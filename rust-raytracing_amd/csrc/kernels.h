@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? (sizeof(R) == 8 ? RT_NESTED
       }
     }
     RT_STAMP(2);
-    if (!to_scatter && active) st.ray = primary_ray<R, C::relaxed()>(sc.camera, fp.width, fp.height, st.pixel, rng);
+    if (!to_scatter && active) st.ray = primary_ray<R, C::relaxed()>(sv.camera(), fp.width, fp.height, st.pixel, rng);
     RT_STAMP(1);
     // an absorbed path (a metal's scattered ray below the surface, src/material.rs:88-90) ends here: it sits out this trace as a
     // miss that adds nothing, and the next turn closes it like any other ended path
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
             active = alive;
           }
         } else {
-          st.ray = primary_ray<R, C::relaxed()>(sc.camera, fp.width, fp.height, st.pixel, rng);
+          st.ray = primary_ray<R, C::relaxed()>(sv.camera(), fp.width, fp.height, st.pixel, rng);
         }
       }
       const bool start = i < 0 && active && resume == 0u;

@@ -53,6 +53,7 @@ template <class R> void layout_sections(BlobLayout& lay) {
   lay.frect_off = off; off = align16(off + (uint32_t)(kFlatMaxLeaves * sizeof(FlatRect)));
   lay.faces_off = off;
   if (lay.flat_mode) off = align16(off + (uint32_t)(6u * lay.n_objects * sizeof(FlatFace<R>)));
+  lay.camera_off = off; off = align16(off + (uint32_t)sizeof(CameraRecord<R>));
   lay.total_bytes = off;
 }
 
@@ -207,6 +208,13 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
       for (int k = 0; k < 3; ++k) P[i].ran[j][k] = (R)s.perlins[i].ran_vec[j][k];
       P[i].perm[0][j] = s.perlins[i].perm_x[j]; P[i].perm[1][j] = s.perlins[i].perm_y[j]; P[i].perm[2][j] = s.perlins[i].perm_z[j];
     }
+  }
+  {
+    CameraRecord<R>& cr = *reinterpret_cast<CameraRecord<R>*>(blob.data() + lay.camera_off);
+    const double* const parts[6] = {s.camera.origin, s.camera.lower_left_corner, s.camera.horizontal, s.camera.vertical, s.camera.u, s.camera.v};
+    for (int v = 0; v < 6; ++v)
+      for (int k = 0; k < 3; ++k) cr.f[3 * v + k] = (R)parts[v][k];
+    cr.f[18] = (R)s.camera.lens_radius; cr.f[19] = (R)s.camera.shutter_open_time; cr.f[20] = (R)s.camera.shutter_close_time;
   }
   HIP_TRY(hipMalloc((void**)&im.d_blob, blob.size()));
   HIP_TRY(hipMemcpy(im.d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
