@@ -256,8 +256,8 @@ template <class R, class C> struct SceneView {
   const DImage* images;
   const CameraRecord<R>* camera_rec;  // global memory, scalar loads
 
-  RT_DEV DCamera<R> camera() const {
-    const CameraRecord<R> r = load_uniform(camera_rec);
+  RT_DEV DCamera<R> camera() const { return camera_of(load_uniform(camera_rec)); }
+  RT_DEV static DCamera<R> camera_of(const CameraRecord<R>& r) {
     DCamera<R> c;
     c.origin = V3<R>(r.f[0], r.f[1], r.f[2]); c.lower_left_corner = V3<R>(r.f[3], r.f[4], r.f[5]);
     c.horizontal = V3<R>(r.f[6], r.f[7], r.f[8]); c.vertical = V3<R>(r.f[9], r.f[10], r.f[11]);

@@ -320,8 +320,13 @@ template <class R> struct PathFeeder {
 #endif
 // CHUNKED: see FrameParams::chunk.  Carrying a chunk's sum costs three registers and a dozen instructions a turn (5-15 % on
 // frames that do not need it), so the launcher picks this variant only for frames made of short, cheap, bright paths.
+// Waves per SIMD asked of the compiler for a double-precision flat-walk kernel (a cap on its registers).  Measured per preset: the
+// smoke kernel wants 150 registers and is 9 % faster squeezed into 128 (four waves); the chunked spheres kernel stands at the edge
+// of 256 (two waves; one register more and it would run a single wave: earth 48 -> 29 Grays/s) and is told to stay below; the
+// unchunked spheres kernel (Perlin noise, simple-light) is 5 % faster with all the registers it wants and one wave.
+template <class C, bool CHUNKED> constexpr int flat_waves_f64() { return C::has(F_MEDIUM) ? 4 : (CHUNKED ? 2 : RT_SMALL_WAVES_F64); }
 template <class R, class C, bool FIXED_GRAB, bool CHUNKED = false>
-__global__ __launch_bounds__(256, C::has(F_NESTED) ? (sizeof(R) == 8 ? RT_NESTED_WAVES_F64 : RT_NESTED_WAVES) : (C::has(F_NOISE) && sizeof(R) == 4 ? RT_NOISE_WAVES : (sizeof(R) == 8 ? RT_SMALL_WAVES_F64 : 1))) void k_paths_persistent(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
+__global__ __launch_bounds__(256, C::has(F_NESTED) ? (sizeof(R) == 8 ? RT_NESTED_WAVES_F64 : RT_NESTED_WAVES) : (C::has(F_NOISE) && sizeof(R) == 4 ? RT_NOISE_WAVES : (sizeof(R) == 8 ? flat_waves_f64<C, CHUNKED>() : 1))) void k_paths_persistent(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
                                                           unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
   extern __shared__ __align__(16) uint8_t lds[];
   const SceneView<R, C> sv = make_view<R, C>(sc, lds);
