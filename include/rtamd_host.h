@@ -58,7 +58,7 @@ void rth_scene_config(const rth_scene* s, uint32_t* width, uint32_t* height, uin
 int rth_scene_from_name(const char* name);
 const char* rth_scene_name(int scene);
 
-/* image.save(path): encoder chosen from the extension (src/render.rs:273-276).  .ppm (P6) and .png are implemented. */
+/* image.save(path): encoder chosen from the extension (src/render.rs:273-276).  .ppm (P6), .png and .jpg / .jpeg (baseline JFIF, quality 75) are implemented. */
 int rth_save_image(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
 /* binary PPM reader used for the pre-decoded earth map */
 int rth_load_ppm(const char* path, uint8_t** rgb8_out, int32_t* width, int32_t* height);

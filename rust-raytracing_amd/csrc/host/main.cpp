@@ -15,7 +15,7 @@ static void usage(const char* argv0) {
                "Usage: %s --no-gui --output <FILE> --scene <SCENE> [options]\n\n"
                "Options:\n"
                "      --no-gui           Use without GUI\n"
-               "  -o, --output <FILE>    Output file (.ppm or .png)\n"
+               "  -o, --output <FILE>    Output file (.ppm, .png or .jpg)\n"
                "  -s, --scene <SCENE>    Scene to render [possible values: random, two-spheres, two-perlin-spheres, earth,\n"
                "                         simple-light, cornell-box, cornell-smoke, final-scene]\n"
                "      --width <N> --aspect <W/H> --spp <N> --depth <N>   override the scene's constants\n"

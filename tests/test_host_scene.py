@@ -157,6 +157,22 @@ def test_image_io_round_trip(rtamd, tmp_path):
         rtamd.save_image(p, img)
         assert np.array_equal(np.asarray(Image.open(p).convert("RGB")), img)
     assert np.array_equal(rtamd.load_ppm(str(tmp_path / "x.ppm")), img)
+    # JPEG is lossy: a smooth picture (sizes that are not multiples of the 8x8 block) comes back within a few levels, and one
+    # of the reference's own renders, re-encoded, within a small mean error.  Byte parity with the image crate's encoder is
+    # unpinned (the crate is not in the reference's tree).
+    yy, xx = np.mgrid[0:45, 0:83]
+    smooth = np.stack([xx * 3, yy * 5, 255 - xx - yy], -1).astype(np.uint8)
+    for ext in ("jpg", "JPEG"):
+        p = str(tmp_path / ("s." + ext))
+        rtamd.save_image(p, smooth)
+        back = np.asarray(Image.open(p).convert("RGB")).astype(int)
+        assert back.shape == smooth.shape and np.abs(back - smooth).max() <= 6 and np.abs(back - smooth).mean() < 1.5
+    rtamd.save_image(str(tmp_path / "n.jpg"), img)            # noise: every coefficient in use, long zero runs absent
+    back = np.asarray(Image.open(str(tmp_path / "n.jpg")).convert("RGB")).astype(int)
+    assert back.shape == img.shape and np.abs(back.mean((0, 1)) - img.mean((0, 1))).max() < 3
+    flat = np.full((16, 24, 3), 255, np.uint8)                # 0xFF bytes in the stream get stuffed
+    rtamd.save_image(str(tmp_path / "f.jpg"), flat)
+    assert np.abs(np.asarray(Image.open(str(tmp_path / "f.jpg")).convert("RGB")).astype(int) - 255).max() <= 1
     with pytest.raises(RuntimeError):
         rtamd.save_image(str(tmp_path / "x.bmp"), img)       # unknown extension, like image.save
     with pytest.raises(RuntimeError):
