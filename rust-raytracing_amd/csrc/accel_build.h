@@ -41,6 +41,11 @@ class FastTreeBuilder {
  public:
   explicit FastTreeBuilder(const rt_scene_desc& s) : s_(s) {}
 
+  // The main tree once more, four children to a node, root first and level by level - filled by build() when no nested tree is
+  // left (every one was dissolved).  `wide_stack_need`: entries the deepest walk can have on its stack.
+  std::vector<WideTmp> wide;
+  int wide_stack_need = 0;
+
   // `ref` are the links of the reference trees before reordering, `ref_root` / `ref_sub_root` their roots.
   // Fills `links` (top-level tree first, then the nested ones), `root` and `sub_root`.
   // `dissolved[o]` != 0: the nested tree held by object o is not built; its objects - which the caller has given o's own
@@ -69,6 +74,7 @@ class FastTreeBuilder {
       for (int child : leaves_in_visiting_order(ref, ref_sub_root[(size_t)o], s_.n_objects)) top.push_back(child);
     }
     Box3d unused;
+    want_wide_ = nested_links.empty() && !std::getenv("RTAMD_NO_WIDE");
     emit_tree(top, 0, links, unused);
     root = 0;
     for (size_t k = 0; k < nested_links.size(); ++k) {
@@ -85,6 +91,7 @@ class FastTreeBuilder {
  private:
   const rt_scene_desc& s_;
   std::vector<Box3d> nested_box_;
+  bool want_wide_ = false;
   std::vector<char> twice_;  // objects whose leaf the reference's tree visits twice and whose second visit matters (media)
   struct Node {
     Box3d box;
@@ -352,6 +359,83 @@ class FastTreeBuilder {
     nodes[(size_t)me].right = r;
   }
 
+  // The binary tree of build_node() folded into nodes of up to four children: a node starts with the two children of its binary
+  // node and, while it has room, replaces the child of largest surface area that is itself an inner node by that node's two
+  // children.  A leaf keeps what the threaded list gives it: the object's own box, except that a sphere of negative radius
+  // stands behind the box of its node in the reference's tree (see guard_box), and a medium the reference visits twice takes two
+  // slots, one per visit (each draws its own free path; the nearer of the two hits wins whichever comes first).
+  struct WideItem { Box3d box; int node; uint32_t word; };
+  void wide_items(const std::vector<Node>& nodes, int n, std::vector<WideItem>& out) const {
+    const Node& nd = nodes[(size_t)n];
+    if (nd.obj < 0) { out.push_back(WideItem{nd.box, n, 0u}); return; }
+    const Box3d b = has_guard(nd.obj) ? guard_box(nd.obj) : nd.box;
+    out.push_back(WideItem{b, -1, leaf_word(nd.obj)});
+    if (!twice_.empty() && twice_[(size_t)nd.obj]) out.push_back(WideItem{b, -1, leaf_word(nd.obj) | LEAF_SECOND});
+  }
+  void build_wide(const std::vector<Node>& nodes) {
+    wide.clear();
+    wide.emplace_back();
+    std::vector<int> queue{0};  // binary node of wide node k
+    std::vector<WideItem> items, grown;
+    for (size_t k = 0; k < queue.size(); ++k) {
+      const Node& nd = nodes[(size_t)queue[k]];
+      items.clear();
+      if (nd.obj >= 0) {
+        wide_items(nodes, queue[k], items);  // a tree of one object
+      } else {
+        wide_items(nodes, nd.left, items);
+        wide_items(nodes, nd.right, items);
+        for (;;) {
+          int pick = -1;
+          double best = -1.0;
+          for (size_t j = 0; j < items.size(); ++j) {
+            if (items[j].node < 0) continue;
+            grown.clear();
+            wide_items(nodes, nodes[(size_t)items[j].node].left, grown);
+            wide_items(nodes, nodes[(size_t)items[j].node].right, grown);
+            if (items.size() - 1 + grown.size() > 4) continue;
+            const double a = items[j].box.area();
+            if (a > best) { best = a; pick = (int)j; }
+          }
+          if (pick < 0) break;
+          grown.clear();
+          wide_items(nodes, nodes[(size_t)items[(size_t)pick].node].left, grown);
+          wide_items(nodes, nodes[(size_t)items[(size_t)pick].node].right, grown);
+          items.erase(items.begin() + pick);
+          items.insert(items.end(), grown.begin(), grown.end());
+        }
+      }
+      WideTmp w{};
+      for (int c = 0; c < 4; ++c) {
+        w.child[c] = kWideNone;
+        for (int a = 0; a < 3; ++a) w.lo[c][a] = w.hi[c][a] = std::numeric_limits<double>::infinity();
+      }
+      for (size_t j = 0; j < items.size(); ++j) {
+        for (int a = 0; a < 3; ++a) { w.lo[j][a] = items[j].box.mn[a]; w.hi[j][a] = items[j].box.mx[a]; }
+        if (items[j].node >= 0) {
+          w.child[j] = (uint32_t)wide.size();
+          wide.emplace_back();
+          queue.push_back(items[j].node);
+        } else {
+          w.child[j] = items[j].word;
+        }
+      }
+      wide[k] = w;
+    }
+    // stack entries the deepest walk can hold: a node with m children leaves m - 1 of them stacked while the walk is below it
+    std::vector<int> need(wide.size(), 0);
+    for (size_t k = wide.size(); k-- > 0;) {
+      int m = 0, below = 0;
+      for (int c = 0; c < 4; ++c) {
+        if (wide[k].child[c] == kWideNone) continue;
+        ++m;
+        if (!(wide[k].child[c] & LEAF_FLAG)) below = std::max(below, need[(size_t)wide[k].child[c]]);
+      }
+      need[k] = std::max(0, m - 1) + below;
+    }
+    wide_stack_need = need[0];
+  }
+
   uint32_t leaf_word(int obj) const {
     const uint32_t f = s_.objects[obj].flags;
     return LEAF_FLAG | ((f & 15u) == 0u ? LEAF_SIMPLE : 0u) | ((f & RT_OBJ_SUB_BVH) ? LEAF_NESTED : 0u) | (uint32_t)obj;
@@ -431,6 +515,10 @@ class FastTreeBuilder {
     build_node(nodes, keep, boxes, 0, (int)keep.size(), 0, spawn_depth);
     mark("split");
     root_box = nodes[0].box;
+    if (tree == 0 && want_wide_) {
+      build_wide(nodes);
+      mark("four-wide form");
+    }
     out.clear();
     out.reserve((size_t)nodes[0].n_links + 2);
     if (nodes[0].obj >= 0) {

@@ -54,6 +54,12 @@ struct TmpLink {
   int32_t depth, tree;
 };
 
+// A node of the four-wide form of the library's own tree before it is packed for the device (device_scene.h: WideNode).
+struct WideTmp {
+  double lo[4][3], hi[4][3];  // [child][axis]
+  uint32_t child[4];          // index of another node, a leaf word, or kWideNone
+};
+
 inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 
 }  // namespace rti
@@ -121,7 +127,7 @@ inline uint32_t grid_for(const rt_context* c, uint64_t n, uint32_t blocks_per_cu
 template <class R> void layout_sections(rtd::BlobLayout& lay);
 template <class R>
 int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink>& links, int root_link, const std::vector<int>& sub_root_of_object,
-                int preset, SceneImage<R>& im);
+                int preset, SceneImage<R>& im, const std::vector<WideTmp>* wide);
 template <class R>
 int render_accum_impl(rt_context* c, const rt_render_params& p, void* accum_dev, rt_stats* stats, unsigned long long* counters_override = nullptr,
                       unsigned long long* host_rays = nullptr);

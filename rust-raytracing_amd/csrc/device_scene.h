@@ -41,6 +41,28 @@ template <class R> struct alignas(16) DLink {  // 32 B (float) / 64 B (double)
 // ray away from cannot be hit by that ray.  Half the bytes per tree entry for the walks that live on memory.
 using BoxLink = DLink<float>;
 
+// A node of the four-wide tree (WALK_LANE_WIDE): the boxes of up to four children and what each child is - the index of another
+// node, or the leaf word of an object (LEAF_FLAG set).  One node is one 128-byte cache line, and a step of the walk is one
+// fetch for four box tests where the threaded list makes four dependent ones.  Single-precision boxes in both images, like
+// BoxLink's.  An unused slot carries the point at +infinity as its box (no ray passes the test) and kWideNone as its child.
+constexpr uint32_t kWideNone = 0xFFFFFFFFu;  // also "no walk in progress" in the walk's state: not a leaf word any tree contains
+struct alignas(128) WideNode {
+  float lo[3][4];  // lo[axis][child]
+  float hi[3][4];
+  uint32_t child[4];
+  uint32_t pad[4];
+};
+// Entries of a lane's stack of the wide walk, one 32-bit child each.  The host refuses the walk (and falls back to the threaded
+// list) for a tree whose worst case needs more: three pushes per level of the path from the root.  36 entries are 144 bytes a
+// lane, which lets four waves per SIMD share a compute unit's 160 KiB of LDS - the walk lives on memory latency, and its speed
+// follows the number of resident waves (measured on the million-sphere field: 5.7 Grays/s at two waves per SIMD, 7.3 at three,
+// 8.1 at four).
+#ifndef RT_WIDE_STACK
+#define RT_WIDE_STACK 36
+#endif
+constexpr uint32_t kWideStack = RT_WIDE_STACK;
+constexpr uint32_t kWideStackBytesPerWave = kWideStack * 64u * 4u;
+
 // tags equal the RT_SHAPE_* / RT_MAT_* / RT_TEX_* / RT_OBJ_* values of rtamd.h
 enum { SH_SPHERE = 0, SH_MOVING = 1, SH_RECT_XY = 2, SH_RECT_XZ = 3, SH_RECT_YZ = 4, SH_BOX = 5 };
 enum { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_LIGHT = 3, MAT_ISOTROPIC = 4, MAT_CLASSES = 5 };
@@ -110,6 +132,7 @@ struct BlobLayout {
   uint32_t n_flat, flat_mode, frect_off, n_frect[3];
   uint32_t faces_off;  // FlatFace records, six per object (flat_mode only)
   uint32_t camera_off; // one CameraRecord
+  uint32_t wide_off, n_wide;  // WideNode records (128-byte aligned), root first; n_wide = 0: the image has no four-wide tree
 };
 
 template <class R> struct DeviceScene {
@@ -169,7 +192,10 @@ enum : uint32_t {
 //   order with a wave-uniform index, so shape and object data arrive through scalar loads and live in scalar registers; every
 //   lane tests every leaf against its own shrinking t_max and no box is tested (see traverse_flat).
 // WALK_LANE: every lane follows its own hit/miss links; the first entries (top tree levels) or the whole scene sit in LDS.
-enum { WALK_UNIFORM = 0, WALK_LANE_LDS_ALL = 1, WALK_LANE_LDS_TOP = 2 };
+// WALK_LANE_WIDE: every lane walks the four-wide tree with a stack of its own in LDS, nearest child first; the scene stays in
+//   global memory.  Only trees of the library's own take it (visiting order depends on the ray, so exact ties may resolve
+//   differently from the reference's fixed order).
+enum { WALK_UNIFORM = 0, WALK_LANE_LDS_ALL = 1, WALK_LANE_LDS_TOP = 2, WALK_LANE_WIDE = 3 };
 constexpr uint32_t kFlatMaxLeaves = 32;
 
 template <uint32_t FEATURES, int WALK> struct Cfg {
@@ -196,10 +222,13 @@ using CfgFlatAllLds = Cfg<F_ALL & ~F_NESTED, WALK_LANE_LDS_ALL>;
 using CfgFlatAllTop = Cfg<F_ALL & ~F_NESTED, WALK_LANE_LDS_TOP>;
 using CfgBallsLds = Cfg<P_BALLS, WALK_LANE_LDS_ALL>;
 using CfgBallsTop = Cfg<P_BALLS, WALK_LANE_LDS_TOP>;
+using CfgBallsWide = Cfg<P_BALLS, WALK_LANE_WIDE>;
+using CfgFlatAllWide = Cfg<F_ALL & ~F_NESTED, WALK_LANE_WIDE>;
 enum {
   PRESET_BOXES = 0, PRESET_SMOKE = 1, PRESET_SPHERES = 2, PRESET_ALL_LDS = 3, PRESET_ALL_TOP = 4, PRESET_BALLS_LDS = 5, PRESET_BALLS_TOP = 6,
   PRESET_FLATALL_LDS = 7, PRESET_FLATALL_TOP = 8,  // images whose nested trees were dissolved (the library's own tree)
-  PRESET_COUNT = 9
+  PRESET_BALLS_WIDE = 9, PRESET_FLATALL_WIDE = 10,  // the library's own tree in its four-wide form
+  PRESET_COUNT = 11
 };
 
 // Read-only record at a wave-uniform address in global memory that no kernel writes (the scene blob): loaded through
@@ -255,6 +284,8 @@ template <class R, class C> struct SceneView {
   const DPerlin<R>* perlins;
   const DImage* images;
   const CameraRecord<R>* camera_rec;  // global memory, scalar loads
+  const WideNode* wide;               // WALK_LANE_WIDE: the four-wide tree (global memory)
+  uint32_t* stack;                    // ... and the stacks of the lane's wave in LDS: child words, [entry][lane]
 
   RT_DEV DCamera<R> camera() const { return camera_of(load_uniform(camera_rec)); }
   RT_DEV static DCamera<R> camera_of(const CameraRecord<R>& r) {
@@ -296,6 +327,7 @@ RT_DEV void stage_to_lds(void* lds, const void* g, uint32_t bytes) {
 template <class R, class C> inline uint32_t lds_bytes_for(const BlobLayout& lay, uint32_t lds_links) {
   if (C::walk == WALK_UNIFORM) return lay.total_bytes;
   if (C::walk == WALK_LANE_LDS_ALL) return lay.total_bytes;
+  if (C::walk == WALK_LANE_WIDE) return 4u * kWideStackBytesPerWave;  // every kernel of these presets runs 256 threads a workgroup
   return lds_links * (uint32_t)sizeof(BoxLink);
 }
 
@@ -317,12 +349,16 @@ template <class R, class C> RT_DEV SceneView<R, C> make_view(const DeviceScene<R
     geom = lds;
     shade = lds;
     lane = lds;
+  } else if constexpr (C::walk == WALK_LANE_WIDE) {
+    // nothing staged: the LDS holds the stacks
   } else {
     stage_to_lds(lds, g + sc.lay.links_off, sc.lds_links * (uint32_t)sizeof(BoxLink));
     v.top = reinterpret_cast<const BoxLink*>(lds);
     v.n_top = sc.lds_links;
   }
   __syncthreads();
+  v.wide = reinterpret_cast<const WideNode*>(g + sc.lay.wide_off);
+  v.stack = reinterpret_cast<uint32_t*>(lds + (threadIdx.x >> 6) * kWideStackBytesPerWave);
   v.n_links = sc.lay.n_links;
   v.links = reinterpret_cast<const BoxLink*>(geom + sc.lay.links_off);
   v.shapes = reinterpret_cast<const DShape<R>*>(geom + sc.lay.shapes_off);

@@ -420,4 +420,105 @@ RT_DEV bool traverse_lane(const SceneView<R, C>& sv, int start, const Ray<R>& ra
   return any;
 }
 
+// ---- four-wide walk (WALK_LANE_WIDE) ----
+// Closest hit over the library's own tree in its four-wide form.  A lane keeps the child it looks at next and a stack of the
+// children still to look at (LDS, [entry][lane] so that the lanes of a wave never share a bank); a step on a node tests the four
+// child boxes against [t_min, closest], goes on with the nearest child that passed and pushes the others, farthest first.  A
+// popped node is tested against the `closest` of that moment like any other, so what a nearer hit has made unreachable falls
+// away one level down.  The closest hit does not depend on the order leaves are tested in (only which of two exactly coincident
+// surfaces is reported does), which is why only the library's own tree, never the reference's, takes this walk.
+RT_DEV void wide_stack_store(uint32_t* base, uint32_t entry, uint32_t lane, uint32_t child) {
+  typedef __attribute__((address_space(3))) uint32_t* lds32;
+  lds32 w = (lds32)(uintptr_t)(uint32_t)(uintptr_t)base;  // the low 32 bits of a generic LDS address are the LDS offset
+  w[entry * 64u + lane] = child;
+}
+RT_DEV uint32_t wide_stack_load(const uint32_t* base, uint32_t entry, uint32_t lane) {
+  typedef const __attribute__((address_space(3))) uint32_t* lds32;
+  lds32 w = (lds32)(uintptr_t)(uint32_t)(uintptr_t)base;
+  return w[entry * 64u + lane];
+}
+
+// Distance at which the ray enters child c's box, +infinity when it misses it inside [t_min, t_max] (an unused slot's box is the
+// point at +infinity, which fails the test).  The distance only orders the children.
+RT_DEV float wide_child_key(const LaneBoxTest<float>& box, const WideNode& nd, int c, const Ray<float>& ray, float t_min, float t_max) {
+  const float x0 = (nd.lo[0][c] - ray.o.x) * box.inv.x, x1 = (nd.hi[0][c] - ray.o.x) * box.inv.x;
+  const float y0 = (nd.lo[1][c] - ray.o.y) * box.inv.y, y1 = (nd.hi[1][c] - ray.o.y) * box.inv.y;
+  const float z0 = (nd.lo[2][c] - ray.o.z) * box.inv.z, z1 = (nd.hi[2][c] - ray.o.z) * box.inv.z;
+  const float tn = rt_max(rt_max(rt_min(x0, x1), rt_min(y0, y1)), rt_max(rt_min(z0, z1), t_min));
+  const float tf = rt_min(rt_min(rt_max(x0, x1), rt_max(y0, y1)), rt_min(rt_max(z0, z1), t_max));
+  return tn < tf ? tn : Lim<float>::inf();
+}
+RT_DEV float wide_child_key(const LaneBoxTest<double>& box, const WideNode& nd, int c, const Ray<double>& ray, double t_min, double t_max) {
+  if (box.plain) {
+    const double x0 = ((double)nd.lo[0][c] - ray.o.x) * box.inv.x, x1 = ((double)nd.hi[0][c] - ray.o.x) * box.inv.x;
+    const double y0 = ((double)nd.lo[1][c] - ray.o.y) * box.inv.y, y1 = ((double)nd.hi[1][c] - ray.o.y) * box.inv.y;
+    const double z0 = ((double)nd.lo[2][c] - ray.o.z) * box.inv.z, z1 = ((double)nd.hi[2][c] - ray.o.z) * box.inv.z;
+    const double tn = rt_max(rt_max(rt_min(x0, x1), rt_min(y0, y1)), rt_max(rt_min(z0, z1), t_min));
+    const double tf = rt_min(rt_min(rt_max(x0, x1), rt_max(y0, y1)), rt_min(rt_max(z0, z1), t_max));
+    return tn < tf ? rt_min((float)tn, 3.0e38f) : Lim<float>::inf();  // finite: +infinity stands for a miss
+  }
+  BoxLink b;  // a ray with a zero direction component: the reference's test as written decides, the order is arbitrary
+  for (int k = 0; k < 3; ++k) { b.bmin[k] = nd.lo[k][c]; b.bmax[k] = nd.hi[k][c]; }
+  return box.hit(b, ray, t_min, t_max) ? 0.0f : Lim<float>::inf();
+}
+
+template <class R> struct WideLane {
+  uint32_t cur = kWideNone;  // node index, leaf word (LEAF_FLAG), or kWideNone: no walk in progress
+  uint32_t sp = 0;
+  RT_DEV bool idle() const { return cur == kWideNone; }
+  RT_DEV bool at_box() const { return !(cur & LEAF_FLAG); }
+  RT_DEV bool at_leaf() const { return (cur & LEAF_FLAG) != 0u && cur != kWideNone; }
+  RT_DEV void start() { cur = 0u; sp = 0u; }
+  RT_DEV void pop(const uint32_t* stack) {
+    cur = kWideNone;
+    if (sp > 0u) { --sp; cur = wide_stack_load(stack, sp, threadIdx.x & 63u); }
+  }
+  // one step on the node `cur`
+  RT_DEV void box_step(const WideNode* wide, uint32_t* stack, const LaneBoxTest<R>& box, const Ray<R>& ray, R t_min, R closest) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const WideNode nd = wide[cur];
+    float key[4];
+    uint32_t ch[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { key[c] = wide_child_key(box, nd, c, ray, t_min, closest); ch[c] = nd.child[c]; }
+    auto order = [&](int a, int b) {
+      const bool s = key[b] < key[a];
+      const float ka = s ? key[b] : key[a], kb = s ? key[a] : key[b];
+      const uint32_t ca = s ? ch[b] : ch[a], cb = s ? ch[a] : ch[b];
+      key[a] = ka; key[b] = kb; ch[a] = ca; ch[b] = cb;
+    };
+    order(0, 1); order(2, 3); order(0, 2); order(1, 3); order(1, 2);  // ascending: key[0] is the nearest
+    const float inf = Lim<float>::inf();
+#pragma unroll
+    for (int c = 3; c >= 1; --c) {
+      if (key[c] < inf && sp < kWideStack) {  // the host guarantees room (kWideStack); the bound keeps a wave inside its own stack regardless
+        wide_stack_store(stack, sp, lane, ch[c]);
+        ++sp;
+      }
+    }
+    if (key[0] < inf) cur = ch[0];
+    else pop(stack);
+  }
+};
+
+template <class R, class C>
+RT_DEV bool traverse_wide(const SceneView<R, C>& sv, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org, Visits* tally) {
+  const LaneBoxTest<R> box(ray);
+  WideLane<R> w;
+  w.start();
+  R closest = t_max;
+  bool any = false;
+  while (!w.idle()) {
+    while (w.at_box()) {
+      if (tally) tally->boxes += 4;  // four boxes, one 128-byte record
+      w.box_step(sv.wide, sv.stack, box, ray, t_min, closest);
+    }
+    if (w.idle()) break;
+    if (tally) ++tally->leaves;
+    if (leaf_hit<R, C, 0>(sv, w.cur, ray, t_min, closest, rec, media, org)) { closest = rec.t; any = true; }
+    w.pop(sv.stack);
+  }
+  return any;
+}
+
 }  // namespace rtd

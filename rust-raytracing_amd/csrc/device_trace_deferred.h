@@ -669,6 +669,8 @@ RT_DEV bool closest_hit(const SceneView<R, C>& sv, int root, const Ray<R>& ray, 
   if constexpr (C::walk == WALK_UNIFORM) {
     if (tally) tally->leaves += sv.n_flat + sv.n_frect[0] + sv.n_frect[1] + sv.n_frect[2];  // every leaf, no box
     return traverse_flat<R, C>(sv, root, ray, t_min, t_max, rec, media, org);
+  } else if constexpr (C::walk == WALK_LANE_WIDE) {
+    return traverse_wide<R, C>(sv, ray, t_min, t_max, rec, media, org, tally);
   } else {
     if constexpr (sizeof(R) == sizeof(float)) return traverse_lane_deferred<C>(sv, root, ray, t_min, t_max, rec, media, org, tally);
     else return traverse_lane<R, C, 0>(sv, root, ray, t_min, t_max, rec, media, org, 0u, tally);

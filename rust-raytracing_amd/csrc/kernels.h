@@ -466,6 +466,10 @@ constexpr uint32_t kLeafLanes = RT_LEAF_LANES;
 constexpr uint32_t kRestartLanes = RT_RESTART_LANES;
 constexpr int kBoxStepsPerTurn = RT_BOX_STEPS;
 constexpr int kTurnsPerCheck = RT_TURNS;
+#ifndef RT_WIDE_STEPS
+#define RT_WIDE_STEPS 1
+#endif
+constexpr int kWideStepsPerTurn = RT_WIDE_STEPS;  // node steps of the four-wide walk between two looks at the waiting leaves
 
 template <class R, class C, bool FIXED_GRAB>
 __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES : (C::has(F_NOISE) ? RT_STEP_WAVES_FULL : RT_STEP_WAVES)) void k_paths_stepwise(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
@@ -480,8 +484,10 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
   unsigned long long n_rays = 0;
   PathState<R> st;
   // walk state of the lane's current ray
-  int i = LINK_END;     // entry to look at next; LINK_END = no walk in progress
+  constexpr bool WIDE = C::walk == WALK_LANE_WIDE;
+  int i = LINK_END;     // entry to look at next; LINK_END = no walk in progress.  Four-wide walk: 0 while `wl` holds a walk
   BoxLink lk{};         // entry i
+  WideLane<R> wl;       // four-wide walk: the child to look at next and the lane's stack
   R closest = Lim<R>::inf();
   bool any = false;
   Rec<R> rec;
@@ -532,8 +538,8 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
       RT_STAMP_COUNT(7, __popcll(__ballot(i < 0)));
       if (start) {
         box = LaneBoxTest<R>(st.ray);
-        i = sc.root_link;
-        lk = sv.link(i);
+        if constexpr (WIDE) { wl.start(); i = 0; }
+        else { i = sc.root_link; lk = sv.link(i); }
         closest = Lim<R>::inf();
         any = false;
         rec = Rec<R>();  // a fresh HitRecord per world.hit call (src/render.rs:157)
@@ -541,6 +547,33 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
       if (__ballot(i >= 0 || resume != 0u) == 0ull) break;  // no walk in progress, no draw unfinished, no path left to start
     }
     RT_STAMP(0);
+    if constexpr (WIDE) {
+#pragma unroll 1
+      for (int turn = 0; turn < kTurnsPerCheck; ++turn) {
+#pragma unroll 1
+        for (int k = 0; k < kWideStepsPerTurn; ++k) {
+          const bool at_box = wl.at_box();
+          if (__ballot(at_box) == 0ull) break;
+          RT_STAMP_COUNT(3, __popcll(__ballot(at_box)));
+          RT_STAMP_COUNT(4, 1);
+          if (at_box) wl.box_step(sv.wide, sv.stack, box, st.ray, (R)0.001, closest);
+        }
+        RT_STAMP(1);
+        const bool at_leaf = wl.at_leaf();
+        const unsigned long long leaf_lanes = __ballot(at_leaf);
+        if ((uint32_t)__popcll(leaf_lanes) < kLeafLanes && __ballot(wl.at_box()) != 0ull) continue;
+        RT_STAMP_COUNT(5, __popcll(leaf_lanes));
+        RT_STAMP_COUNT(6, 1);
+        if (at_leaf) {
+          Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
+          if (leaf_hit<R, C, 0>(sv, wl.cur, st.ray, (R)0.001, closest, rec, media, st.org)) { closest = rec.t; any = true; }
+          wl.pop(sv.stack);
+        }
+        RT_STAMP(2);
+      }
+      if (wl.idle()) i = LINK_END;
+      continue;
+    }
 #pragma unroll 1
     for (int turn = 0; turn < kTurnsPerCheck; ++turn) {
 #pragma unroll 1

@@ -16,6 +16,8 @@ template <class R> KernelTable<R> table_for(int preset) {
     case PRESET_BALLS_TOP: return kernel_table<R, PRESET_BALLS_TOP>();
     case PRESET_FLATALL_LDS: return kernel_table<R, PRESET_FLATALL_LDS>();
     case PRESET_FLATALL_TOP: return kernel_table<R, PRESET_FLATALL_TOP>();
+    case PRESET_BALLS_WIDE: return kernel_table<R, PRESET_BALLS_WIDE>();
+    case PRESET_FLATALL_WIDE: return kernel_table<R, PRESET_FLATALL_WIDE>();
     default: break;
   }
   return kernel_table<R, PRESET_ALL_TOP>();
@@ -24,6 +26,8 @@ template <class R> KernelTable<R> table_for(int preset) {
 static_assert(sizeof(RayIO) == sizeof(rt_ray), "rt_ray layout");
 static_assert(sizeof(HitIO) == sizeof(rt_hit), "rt_hit layout");
 static_assert(sizeof(DLink<float>) == 32 && sizeof(DLink<double>) == 64, "link size");
+static_assert(sizeof(WideNode) == 128, "wide node size");
+
 
 template <class R> R round_down(double x);
 template <class R> R round_up(double x);
@@ -54,12 +58,14 @@ template <class R> void layout_sections(BlobLayout& lay) {
   lay.faces_off = off;
   if (lay.flat_mode) off = align16(off + (uint32_t)(6u * lay.n_objects * sizeof(FlatFace<R>)));
   lay.camera_off = off; off = align16(off + (uint32_t)sizeof(CameraRecord<R>));
+  lay.wide_off = (off + 127u) & ~127u;
+  if (lay.n_wide) off = lay.wide_off + lay.n_wide * (uint32_t)sizeof(WideNode);
   lay.total_bytes = off;
 }
 
 template <class R>
 int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink>& links, int root_link, const std::vector<int>& sub_root_of_object,
-                int preset, SceneImage<R>& im) {
+                int preset, SceneImage<R>& im, const std::vector<WideTmp>* wide) {
   BlobLayout lay{};
   lay.n_links = (uint32_t)links.size();
   lay.n_objects = (uint32_t)s.n_objects;
@@ -104,7 +110,38 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
   lay.n_flat = (uint32_t)others.size();
   for (int k = 0; k < 3; ++k) lay.n_frect[k] = (uint32_t)frects[k].size();
   layout_sections<R>(lay);
+  // The four-wide form of the library's own tree replaces the threaded list where the image does not fit in LDS (there the list
+  // is walked from LDS and is the faster of the two).  RTAMD_WIDE_ALWAYS=1: wherever a wide tree exists (measurement switch).
+  if (wide && !wide->empty() && (preset == PRESET_BALLS_LDS || preset == PRESET_FLATALL_LDS) &&
+      (lay.total_bytes > kLdsAllMax || getenv("RTAMD_WIDE_ALWAYS"))) {
+    preset = preset == PRESET_BALLS_LDS ? PRESET_BALLS_WIDE : PRESET_FLATALL_WIDE;
+    lay.n_wide = (uint32_t)wide->size();
+    layout_sections<R>(lay);
+  }
   std::vector<uint8_t> blob(lay.total_bytes, 0);
+  if (lay.n_wide) {
+    WideNode* W = reinterpret_cast<WideNode*>(blob.data() + lay.wide_off);
+    const float inf = std::numeric_limits<float>::infinity();
+    for (size_t i = 0; i < wide->size(); ++i) {
+      const WideTmp& w = (*wide)[i];
+      // a child takes part unless its slot is unused or its box is inverted along some axis (see the links below: no ray passes)
+      bool used[4];
+      for (int ch = 0; ch < 4; ++ch)
+        used[ch] = w.child[ch] != kWideNone && !(w.lo[ch][0] > w.hi[ch][0] || w.lo[ch][1] > w.hi[ch][1] || w.lo[ch][2] > w.hi[ch][2]);
+      WideNode& n = W[i];
+      std::memset(&n, 0, sizeof(n));
+      for (int ch = 0; ch < 4; ++ch) {
+        n.child[ch] = used[ch] ? w.child[ch] : kWideNone;
+        for (int k = 0; k < 3; ++k) {
+          n.lo[k][ch] = used[ch] ? round_down<float>(w.lo[ch][k]) : inf;
+          n.hi[k][ch] = used[ch] ? round_up<float>(w.hi[ch][k]) : inf;
+        }
+        // a re-centred sphere's front_face rule is read from the object's flags, which the walk looks at only when the leaf is
+        // not marked simple (the wide walk fills its records as the double-precision list walk does, in both precisions)
+        if (used[ch] && (w.child[ch] & LEAF_FLAG) && (s.objects[w.child[ch] & LEAF_INDEX_MASK].flags & OBJ_FRONT_CHAIN)) n.child[ch] &= ~LEAF_SIMPLE;
+      }
+    }
+  }
   if (lay.flat_mode) {
     FlatFace<R>* F = reinterpret_cast<FlatFace<R>*>(blob.data() + lay.faces_off);
     for (int i = 0; i < s.n_objects; ++i) {
@@ -541,7 +578,8 @@ template <class R> int resolve_impl(rt_context* c, const void* accum_dev, size_t
 
 #define RTI_INSTANTIATE(R)                                                                                                                   \
   template void layout_sections<R>(BlobLayout&);                                                                                        \
-  template int build_image<R>(rt_context*, const rt_scene_desc&, const std::vector<TmpLink>&, int, const std::vector<int>&, int, SceneImage<R>&); \
+  template int build_image<R>(rt_context*, const rt_scene_desc&, const std::vector<TmpLink>&, int, const std::vector<int>&, int, SceneImage<R>&, \
+                              const std::vector<WideTmp>*);                                                                              \
   template int render_accum_impl<R>(rt_context*, const rt_render_params&, void*, rt_stats*, unsigned long long*, unsigned long long*);                                              \
   template int trace_batch_impl<R>(rt_context*, const rt_ray*, size_t, rt_hit*, uint64_t, int);                                                   \
   template int pairs_kernel_impl<R>(rt_context*, int, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint32_t*, size_t, uint64_t, void*, \

@@ -267,6 +267,44 @@ def test_f32_tree_variants_agree(gpu, rtamd, oracle, earth_rgb, name, switch, mo
 
 
 
+@pytest.mark.parametrize("name,kw,switch", [("final-scene", {}, "RTAMD_NO_WIDE"), ("final-scene", {"bvh_seed": 13}, "RTAMD_NO_WIDE"),
+                                            ("random", {}, "RTAMD_NO_WIDE"), ("mega-spheres", {"mega_grid": 60, "width": 160, "spp": 4}, "RTAMD_NO_WIDE")])
+def test_wide_walk_and_list_walk_agree(gpu, rtamd, oracle, earth_rgb, name, kw, switch, monkeypatch):
+    """The library's own tree is walked in its four-wide form (a stack per lane, nearest child first) where the image does not fit
+    in LDS, and as a threaded list (fixed order) where it does.  Both must report the same closest hit in both precisions: ids
+    equal except on exactly coincident surfaces, where the order of the tests decides, and the same distance.  With axis seed 13
+    final-scene has a medium the reference visits twice (two slots of a wide node, two entries of the list)."""
+    hs, _ = make_pair(rtamd, oracle, name, earth=earth_rgb, **kw)
+    rng = np.random.default_rng(1357)
+    lo, hi = SCENE_BOXES.get(name, ((-60, 0.05, -60), (60, 3, 60)))
+    rays = random_rays(rng, 100_000, lo, hi)
+    presets = []
+    out = []
+    for on in (False, True):
+        if on:
+            monkeypatch.setenv(switch, "1")
+        gpu.upload(hs)
+        out.append((gpu.trace_batch(rays, precision=rtamd.F32, seed=5, as_rendered=True), gpu.trace_batch(rays, precision=rtamd.F64_OWN_TREE, seed=5)))
+        presets.append(gpu.render_accum(None, 0, 1, precision=rtamd.F32, seed=3)["scene_in_lds"])
+    monkeypatch.delenv(switch)
+    gpu.upload(hs)
+    assert sum(p in (9, 10) for p in presets) == 1, presets  # one of the two images took a four-wide preset
+    for k, tol in ((0, 1e-6), (1, 1e-14)):
+        a, b = out[0][k], out[1][k]
+        same = np.ones(rays.size, dtype=bool)
+        for f in ID_FIELDS:
+            same &= a[f] == b[f]
+        tie = (a["hit"] == 1) & (b["hit"] == 1) & (np.abs(a["t"] - b["t"]) <= tol * np.abs(a["t"]))
+        print("\n%s %s: %d of %d rays differ in ids between the two walks, %d of them not ties" % (name, "f64" if k else "f32", int((~same).sum()), rays.size, int((~(same | tie)).sum())))
+        assert (same | tie).all() and (~same).mean() < 2e-3
+        both = same & (a["hit"] == 1)
+        if k:  # double: the same leaf code either way, bit for bit
+            assert np.array_equal(a["t"][both], b["t"][both]) and np.array_equal(a["p"][both], b["p"][both]) and np.array_equal(a["n"][both], b["n"][both])
+        else:  # single: the list walk builds its record after the walk, the wide walk as it goes (hardware reciprocals in different places)
+            assert (np.abs(a["t"][both] - b["t"][both]) / np.abs(a["t"][both])).max() < 1e-6
+            assert np.abs(a["n"][both] - b["n"][both]).max() < 1e-4
+
+
 @pytest.mark.parametrize("name,mega_grid", [("random", 0), ("final-scene", 0), ("mega-spheres", 40), ("cornell-box", 0)])
 def test_f64_on_the_librarys_own_tree(gpu, rtamd, oracle, earth_rgb, name, mega_grid):
     """RT_F64_OWN_TREE: double arithmetic on the tree the library builds for itself.  Checked against the ORACLE like the default
