@@ -388,12 +388,14 @@ class FastTreeBuilder {
         for (;;) {
           int pick = -1;
           double best = -1.0;
+          auto slots = [&](int n) {  // slots the binary node n takes as a child: one, or two for a medium visited twice
+            const Node& c = nodes[(size_t)n];
+            return (c.obj >= 0 && !twice_.empty() && twice_[(size_t)c.obj]) ? 2u : 1u;
+          };
           for (size_t j = 0; j < items.size(); ++j) {
             if (items[j].node < 0) continue;
-            grown.clear();
-            wide_items(nodes, nodes[(size_t)items[j].node].left, grown);
-            wide_items(nodes, nodes[(size_t)items[j].node].right, grown);
-            if (items.size() - 1 + grown.size() > 4) continue;
+            const Node& in = nodes[(size_t)items[j].node];
+            if (items.size() - 1 + slots(in.left) + slots(in.right) > 4) continue;
             const double a = items[j].box.area();
             if (a > best) { best = a; pick = (int)j; }
           }

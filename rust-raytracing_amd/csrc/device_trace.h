@@ -501,24 +501,4 @@ template <class R> struct WideLane {
   }
 };
 
-template <class R, class C>
-RT_DEV bool traverse_wide(const SceneView<R, C>& sv, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org, Visits* tally) {
-  const LaneBoxTest<R> box(ray);
-  WideLane<R> w;
-  w.start();
-  R closest = t_max;
-  bool any = false;
-  while (!w.idle()) {
-    while (w.at_box()) {
-      if (tally) tally->boxes += 4;  // four boxes, one 128-byte record
-      w.box_step(sv.wide, sv.stack, box, ray, t_min, closest);
-    }
-    if (w.idle()) break;
-    if (tally) ++tally->leaves;
-    if (leaf_hit<R, C, 0>(sv, w.cur, ray, t_min, closest, rec, media, org)) { closest = rec.t; any = true; }
-    w.pop(sv.stack);
-  }
-  return any;
-}
-
 }  // namespace rtd

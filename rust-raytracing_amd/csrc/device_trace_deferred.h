@@ -662,6 +662,45 @@ RT_DEV bool traverse_lane_deferred(const SceneView<float, C>& sv, int start, con
   return true;
 }
 
+// The four-wide walk of one ray from start to end (the path kernels step through it instead: k_paths_stepwise), records built as
+// k_paths_stepwise builds them (Cfg::defer_records).
+template <class R, class C>
+RT_DEV bool traverse_wide(const SceneView<R, C>& sv, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org, Visits* tally) {
+  constexpr bool DEFER = sizeof(R) == sizeof(float) && C::defer_records();
+  const LaneBoxTest<R> box(ray);
+  WideLane<R> w;
+  w.start();
+  R closest = t_max;
+  bool any = false;
+  int best_leaf = -1, best_side = -1;
+  while (!w.idle()) {
+    while (w.at_box()) {
+      if (tally) tally->boxes += 4;  // four boxes, one 128-byte record
+      w.box_step(sv.wide, sv.stack, box, ray, t_min, closest);
+    }
+    if (w.idle()) break;
+    if (tally) ++tally->leaves;
+    if constexpr (DEFER) {
+      RayInv<R> ri(ray.d);
+      ri.inv = box.inv;
+      R t;
+      int side;
+      if (leaf_t<R, C>(sv, w.cur, ray, ri, t_min, closest, media, org, t, side, visit_bit(w.cur, 0))) {
+        closest = t; best_leaf = (int)(w.cur & LEAF_INDEX_MASK); best_side = side;
+      }
+    } else {
+      if (leaf_hit<R, C, 0>(sv, w.cur, ray, t_min, closest, rec, media, org)) { closest = rec.t; any = true; }
+    }
+    w.pop(sv.stack);
+  }
+  if constexpr (DEFER) {
+    if (best_leaf < 0) return false;
+    finalize_hit<R, C>(sv, ray, closest, best_leaf, best_side, rec);
+    return true;
+  }
+  return any;
+}
+
 // world.hit(ray, t_min, t_max, rec).  May be called from divergent code: lanes without a ray simply do not take part.
 template <class R, class C>
 RT_DEV bool closest_hit(const SceneView<R, C>& sv, int root, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org,

@@ -488,16 +488,43 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
   int i = LINK_END;     // entry to look at next; LINK_END = no walk in progress.  Four-wide walk: 0 while `wl` holds a walk
   BoxLink lk{};         // entry i
   WideLane<R> wl;       // four-wide walk: the child to look at next and the lane's stack
+  // Single precision, presets with boxes / wrappers / media (Cfg::defer_records): the winning candidate is kept as (closest, leaf,
+  // side) while the walk lasts and the record is built once, when the lane is shaded (device_trace_deferred.h).  Double precision
+  // fills the record at every accepted candidate, as the reference does (a hit that writes no (u, v) must find the ones an earlier
+  // candidate left).
+  constexpr bool DEFER = sizeof(R) == sizeof(float) && C::defer_records();
+  int best_leaf = -1, best_side = -1;
   R closest = Lim<R>::inf();
   bool any = false;
   Rec<R> rec;
   LaneBoxTest<R> box(Ray<R>{});
+  // the test of one leaf against the lane's ray
+  auto step_leaf = [&](uint32_t word, Stream& media) {
+    if constexpr (DEFER) {
+      RayInv<R> ri(st.ray.d);
+      ri.inv = box.inv;
+      R t;
+      int side;
+      if (leaf_t<R, C>(sv, word, st.ray, ri, (R)0.001, closest, media, st.org, t, side, visit_bit(word, 0))) {
+        closest = t; best_leaf = (int)(word & LEAF_INDEX_MASK); best_side = side;
+      }
+    } else {
+      if (leaf_hit<R, C, 0>(sv, word, st.ray, (R)0.001, closest, rec, media, st.org)) { closest = rec.t; any = true; }
+    }
+  };
   RT_STAMP_INIT();  // diagnostic build: cycles of [0] restart blocks, [1] box steps, [2] leaf steps; lanes taking part in [3] box steps,
                     // [5] leaf steps, [7] restarts, and the number of [4] box steps, [6] leaf steps (restarts: [7] / lanes per restart)
   for (;;) {
     const unsigned long long idle = __ballot(i < 0);
     if ((uint32_t)__popcll(idle) >= kRestartLanes || idle == ~0ull) {
       bool to_scatter = false;
+      if constexpr (DEFER) {
+        if (i < 0 && active && best_leaf >= 0) {  // the walk has ended on a hit: its record, once
+          finalize_hit<R, C>(sv, st.ray, closest, best_leaf, best_side, rec);
+          any = true;
+          best_leaf = -1;
+        }
+      }
       if (i < 0 && active) {
         if (!any) {
           add_radiance(accum, st.pixel, st.thr * background_color<R, C>(sc.background, st.ray.d));
@@ -542,6 +569,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
         else { i = sc.root_link; lk = sv.link(i); }
         closest = Lim<R>::inf();
         any = false;
+        best_leaf = -1;
         rec = Rec<R>();  // a fresh HitRecord per world.hit call (src/render.rs:157)
       }
       if (__ballot(i >= 0 || resume != 0u) == 0ull) break;  // no walk in progress, no draw unfinished, no path left to start
@@ -566,7 +594,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
         RT_STAMP_COUNT(6, 1);
         if (at_leaf) {
           Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
-          if (leaf_hit<R, C, 0>(sv, wl.cur, st.ray, (R)0.001, closest, rec, media, st.org)) { closest = rec.t; any = true; }
+          step_leaf(wl.cur, media);
           wl.pop(sv.stack);
         }
         RT_STAMP(2);
@@ -597,7 +625,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
       RT_STAMP_COUNT(6, 1);
       if (at_leaf) {
         Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
-        if (leaf_hit<R, C, 0>(sv, lk.hit, st.ray, (R)0.001, closest, rec, media, st.org)) { closest = rec.t; any = true; }
+        step_leaf(lk.hit, media);
         i = lk.miss;
         if (i >= 0) lk = sv.link(i);
       }

@@ -136,9 +136,9 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
           n.lo[k][ch] = used[ch] ? round_down<float>(w.lo[ch][k]) : inf;
           n.hi[k][ch] = used[ch] ? round_up<float>(w.hi[ch][k]) : inf;
         }
-        // a re-centred sphere's front_face rule is read from the object's flags, which the walk looks at only when the leaf is
-        // not marked simple (the wide walk fills its records as the double-precision list walk does, in both precisions)
-        if (used[ch] && (w.child[ch] & LEAF_FLAG) && (s.objects[w.child[ch] & LEAF_INDEX_MASK].flags & OBJ_FRONT_CHAIN)) n.child[ch] &= ~LEAF_SIMPLE;
+        // see the links below: a re-centred sphere's front_face rule is read from the object's flags (such spheres come with wrapped
+        // objects, so the single-precision walk of their preset builds its records after the walk and reads the flags there)
+        if (!single && used[ch] && (w.child[ch] & LEAF_FLAG) && (s.objects[w.child[ch] & LEAF_INDEX_MASK].flags & OBJ_FRONT_CHAIN)) n.child[ch] &= ~LEAF_SIMPLE;
       }
     }
   }

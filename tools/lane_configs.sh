@@ -1,0 +1,9 @@
+set -e
+cd "$GRAFT_REPO_ROOT"; OUT=gpurun_out/r2b_lane_configs.jsonl; : > $OUT
+run() { timeout -k 10 400 python3 bench.py --steps 2 --warmup 1 "$@" 2>>gpurun_out/r2b_lane.err | grep '^{"metric"' >> "$OUT"; }
+run --scene random --spp 64 --no-cpu-baseline
+run --scene final-scene --spp 64 --no-cpu-baseline
+run --scene mega-spheres --mega-grid 500 --width 3840 --spp 16 --no-cpu-baseline
+run --scene random --width 400 --spp 100 --no-cpu-baseline
+run --scene final-scene --width 800 --aspect 1.0 --spp 64 --no-cpu-baseline
+python3 tools/configs_table.py $OUT
