@@ -207,11 +207,15 @@ template <uint32_t FEATURES, int WALK> struct Cfg {
   // that would amplify the difference, so paths still follow the reference arithmetic's to ~1e-13; the per-lane presets, whose
   // scenes do have such clusters, keep the IEEE forms everywhere.
   static constexpr bool relaxed() { return WALK == 0; }
-  // Single-precision per-lane walks that step through the tree (k_paths_stepwise, traverse_wide): keep the winning candidate as
-  // (t, leaf, side) and build the record once, after the walk, where a record per accepted candidate is costly - boxes (six
-  // rectangle records), wrappers, media (two boundary records per test); final-scene +17 %.  Sphere-only presets fill the record
-  // as they go: there the deferred form measures 3-4 % slower.
-  static constexpr bool defer_records() { return has(F_BOX) || has(F_MEDIUM) || has(F_XFORM); }
+  // Per-lane walks that step through the tree (k_paths_stepwise, traverse_wide): keep the winning candidate as (t, leaf, side) and
+  // build the record once, after the walk, where a record per accepted candidate is costly - boxes (six rectangle records),
+  // wrappers, media (two boundary records per test); final-scene +17 % in single precision.  Sphere-only presets fill the record
+  // as they go: there the deferred form measures 3-4 % slower.  Double precision on the caller's tree always fills the record as
+  // it goes, as the reference does (a hit that writes no (u, v) must find the ones an earlier candidate left); on the library's
+  // own tree (the four-wide walk) the order of the candidates is not the reference's anyway, and it defers like single precision.
+  template <class R> static constexpr bool defer_records() {
+    return (has(F_BOX) || has(F_MEDIUM) || has(F_XFORM)) && (sizeof(R) == sizeof(float) || WALK == 3);
+  }
 };
 constexpr uint32_t P_BOXES = F_RECT | F_BOX | F_XFORM;                                  // cornell-box
 constexpr uint32_t P_SMOKE = P_BOXES | F_MEDIUM;                                        // cornell-smoke

@@ -666,7 +666,7 @@ RT_DEV bool traverse_lane_deferred(const SceneView<float, C>& sv, int start, con
 // k_paths_stepwise builds them (Cfg::defer_records).
 template <class R, class C>
 RT_DEV bool traverse_wide(const SceneView<R, C>& sv, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org, Visits* tally) {
-  constexpr bool DEFER = sizeof(R) == sizeof(float) && C::defer_records();
+  constexpr bool DEFER = C::template defer_records<R>();
   const LaneBoxTest<R> box(ray);
   WideLane<R> w;
   w.start();

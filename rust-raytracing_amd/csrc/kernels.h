@@ -492,7 +492,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
   // side) while the walk lasts and the record is built once, when the lane is shaded (device_trace_deferred.h).  Double precision
   // fills the record at every accepted candidate, as the reference does (a hit that writes no (u, v) must find the ones an earlier
   // candidate left).
-  constexpr bool DEFER = sizeof(R) == sizeof(float) && C::defer_records();
+  constexpr bool DEFER = C::template defer_records<R>();
   int best_leaf = -1, best_side = -1;
   R closest = Lim<R>::inf();
   bool any = false;
