@@ -60,6 +60,26 @@ struct WideTmp {
   uint32_t child[4];          // index of another node, a leaf word, or kWideNone
 };
 
+// A hit that does not write (u, v) - a moving sphere (src/moving_sphere.rs:44-72), a medium (src/constant_medium.rs:97-108) -
+// reports whatever an earlier accepted candidate left in the reference's shared record.  Only an image texture reads (u, v):
+// true when one sits on such an object.
+inline bool reads_leftover_uv(const rt_scene_desc& s) {
+  auto reads_uv = [&](int mat) {
+    if (mat < 0 || mat >= s.n_materials) return false;
+    const int tx = s.materials[mat].texture;
+    if (tx < 0 || tx >= s.n_textures) return false;
+    const rt_texture& t = s.textures[tx];
+    auto image = [&](int k) { return k >= 0 && k < s.n_textures && s.textures[k].tag == RT_TEX_IMAGE; };
+    return t.tag == RT_TEX_IMAGE || (t.tag == RT_TEX_CHECKER && (image(t.even) || image(t.odd)));
+  };
+  for (int i = 0; i < s.n_objects; ++i) {
+    const rt_object& o = s.objects[i];
+    if ((o.flags & RT_OBJ_MEDIUM) && reads_uv(o.medium_material)) return true;
+    if (!(o.flags & RT_OBJ_SUB_BVH) && s.shapes[o.geom].tag == RT_SHAPE_MOVING_SPHERE && reads_uv(s.shapes[o.geom].material)) return true;
+  }
+  return false;
+}
+
 inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 
 }  // namespace rti

@@ -142,6 +142,7 @@ template <class R> struct DeviceScene {
   int32_t n_images;
   int32_t root_link;
   uint32_t lds_links;  // number of leading links staged in LDS when the blob is not staged whole
+  uint32_t defer_ok;   // no texture of the scene reads the (u, v) a moving sphere or a medium inherits from an earlier candidate
   DCamera<R> camera;
   DBackground<R> background;
 };
@@ -213,9 +214,11 @@ template <uint32_t FEATURES, int WALK> struct Cfg {
   // as they go: there the deferred form measures 3-4 % slower.  Double precision on the caller's tree always fills the record as
   // it goes, as the reference does (a hit that writes no (u, v) must find the ones an earlier candidate left); on the library's
   // own tree (the four-wide walk) the order of the candidates is not the reference's anyway, and it defers like single precision.
-  template <class R> static constexpr bool defer_records() {
-    return (has(F_BOX) || has(F_MEDIUM) || has(F_XFORM)) && (sizeof(R) == sizeof(float) || WALK == 3);
-  }
+  // The path kernel has a deferring variant for the caller's tree in double precision as well, launched when nothing in the scene
+  // reads such a leftover (DeviceScene::defer_ok): every other field of the record is a function of the ray, the winning leaf and
+  // its t alone.
+  static constexpr bool costly_records() { return has(F_BOX) || has(F_MEDIUM) || has(F_XFORM); }
+  template <class R> static constexpr bool defer_records() { return costly_records() && (sizeof(R) == sizeof(float) || WALK == 3); }
 };
 constexpr uint32_t P_BOXES = F_RECT | F_BOX | F_XFORM;                                  // cornell-box
 constexpr uint32_t P_SMOKE = P_BOXES | F_MEDIUM;                                        // cornell-smoke

@@ -34,6 +34,11 @@ constexpr uint32_t kBlockThreads = 256;
 #endif
 // The chunked variant of the persistent kernel exists for the small sphere scenes only (see render_accum_impl for when it runs).
 template <class C> constexpr bool chunked_variant() { return C::walk == WALK_UNIFORM && C::has(F_SPHERE); }
+// Double precision on the caller's tree: the stepwise kernel has a second instantiation that builds its records after the walk,
+// launched for scenes in which no texture reads a leftover (u, v) (DeviceScene::defer_ok).
+template <class R, class C> constexpr bool list_defer_variant() {
+  return sizeof(R) == 8 && C::walk != WALK_UNIFORM && C::walk != WALK_LANE_WIDE && !C::has(F_NESTED) && C::costly_records();
+}
 template <class C> constexpr bool use_stepwise() { return C::walk != WALK_UNIFORM && (RT_STEPWISE_NESTED || !C::has(F_NESTED)); }
 
 template <class R, class C> KernelTable<R> make_table() {
@@ -58,6 +63,13 @@ template <class R, class C> KernelTable<R> make_table() {
       else hipLaunchKernelGGL((k_paths_persistent<R, C, false>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
     }
     else {
+      if constexpr (list_defer_variant<R, C>()) {
+        if (sc.defer_ok) {
+          if (fixed) hipLaunchKernelGGL((k_paths_stepwise<R, C, true, true>), dim3(grid), dim3(kStepThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
+          else hipLaunchKernelGGL((k_paths_stepwise<R, C, false, true>), dim3(grid), dim3(kStepThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
+          return;
+        }
+      }
       if (fixed) hipLaunchKernelGGL((k_paths_stepwise<R, C, true>), dim3(grid), dim3(kStepThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
       else hipLaunchKernelGGL((k_paths_stepwise<R, C, false>), dim3(grid), dim3(kStepThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
     }

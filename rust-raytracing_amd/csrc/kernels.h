@@ -450,6 +450,9 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? (sizeof(R) == 8 ? RT_NESTED
 #ifndef RT_STEP_WAVES_FULL
 #define RT_STEP_WAVES_FULL 4
 #endif
+#ifndef RT_STEP_WAVES_FULL_F64
+#define RT_STEP_WAVES_FULL_F64 3  // double precision: final-scene on the library's tree 3.71 / 3.95 / 3.83 Grays/s at 4 / 3 / 2 waves per SIMD, on the caller's tree no difference
+#endif
 #ifndef RT_STEP_THREADS
 #define RT_STEP_THREADS 256
 #endif
@@ -471,8 +474,8 @@ constexpr int kTurnsPerCheck = RT_TURNS;
 #endif
 constexpr int kWideStepsPerTurn = RT_WIDE_STEPS;  // node steps of the four-wide walk between two looks at the waiting leaves
 
-template <class R, class C, bool FIXED_GRAB>
-__global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES : (C::has(F_NOISE) ? RT_STEP_WAVES_FULL : RT_STEP_WAVES)) void k_paths_stepwise(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
+template <class R, class C, bool FIXED_GRAB, bool DEFER_LIST = false>
+__global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES : (C::has(F_NOISE) ? (sizeof(R) == 8 ? RT_STEP_WAVES_FULL_F64 : RT_STEP_WAVES_FULL) : RT_STEP_WAVES)) void k_paths_stepwise(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
                                                         unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
   extern __shared__ __align__(16) uint8_t lds[];
   const SceneView<R, C> sv = make_view<R, C>(sc, lds);
@@ -490,9 +493,9 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
   WideLane<R> wl;       // four-wide walk: the child to look at next and the lane's stack
   // Single precision, presets with boxes / wrappers / media (Cfg::defer_records): the winning candidate is kept as (closest, leaf,
   // side) while the walk lasts and the record is built once, when the lane is shaded (device_trace_deferred.h).  Double precision
-  // fills the record at every accepted candidate, as the reference does (a hit that writes no (u, v) must find the ones an earlier
-  // candidate left).
-  constexpr bool DEFER = C::template defer_records<R>();
+  // on the caller's tree fills the record at every accepted candidate, as the reference does (a hit that writes no (u, v) must find
+  // the ones an earlier candidate left), unless the launcher knows that nothing reads such a leftover (DEFER_LIST).
+  constexpr bool DEFER = C::template defer_records<R>() || (DEFER_LIST && C::costly_records());
   int best_leaf = -1, best_side = -1;
   R closest = Lim<R>::inf();
   bool any = false;

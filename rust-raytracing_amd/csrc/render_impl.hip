@@ -266,6 +266,7 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
   d.images = c->d_images;
   d.n_images = s.n_images;
   d.root_link = root_link;
+  d.defer_ok = (reads_leftover_uv(s) || getenv("RTAMD_EAGER_RECORDS")) ? 0u : 1u;
   uint32_t top_bytes = kLdsTopMax;
   if (const char* e = getenv("RTAMD_TOP_LDS_BYTES")) top_bytes = (uint32_t)std::max(0, atoi(e));  // measurement switch
   d.lds_links = (preset == PRESET_ALL_TOP || preset == PRESET_BALLS_TOP || preset == PRESET_FLATALL_TOP) ? std::min<uint32_t>(lay.n_links, top_bytes / (uint32_t)sizeof(BoxLink)) : 0u;

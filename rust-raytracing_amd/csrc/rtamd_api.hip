@@ -509,20 +509,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   // One thing does change: a hit that does not write (u, v) - a moving sphere, a medium - reports whatever an earlier accepted hit
   // left in the reference's shared record, and with fewer accepted hits on the way that leftover can be another.  Only an image
   // texture reads (u, v): with one on such an object the copies stay.
-  bool stale_uv_read = false;
-  for (int i = 0; i < s->n_objects; ++i) {
-    const rt_object& o = s->objects[i];
-    auto reads_uv = [&](int mat) {
-      if (mat < 0 || mat >= s->n_materials) return false;
-      const int tx = s->materials[mat].texture;
-      if (tx < 0 || tx >= s->n_textures) return false;
-      const rt_texture& t = s->textures[tx];
-      auto image = [&](int k) { return k >= 0 && k < s->n_textures && s->textures[k].tag == RT_TEX_IMAGE; };
-      return t.tag == RT_TEX_IMAGE || (t.tag == RT_TEX_CHECKER && (image(t.even) || image(t.odd)));
-    };
-    if (o.flags & RT_OBJ_MEDIUM) stale_uv_read = stale_uv_read || reads_uv(o.medium_material);
-    if (!(o.flags & RT_OBJ_SUB_BVH) && s->shapes[o.geom].tag == RT_SHAPE_MOVING_SPHERE) stale_uv_read = stale_uv_read || reads_uv(s->shapes[o.geom].material);
-  }
+  const bool stale_uv_read = reads_leftover_uv(*s);
   if (!uniform && !stale_uv_read && !std::getenv("RTAMD_KEEP_COPIES")) {
     FastTreeBuilder sig(*s);
     std::vector<int> order;
