@@ -63,8 +63,8 @@ def cpu_share():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scene", default="cornell-box")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--aspect", type=float, default=16.0 / 9.0)

@@ -262,6 +262,37 @@ def test_many_perlin_tables_leave_the_small_scene_preset(gpu, rtamd, oracle):
             assert abs(np.clip(got / 4, 0, 1).mean() - np.clip(want / 4, 0, 1).mean()) < 2e-3 * np.clip(want / 4, 0, 1).mean()
 
 
+def test_records_built_after_the_walk_render_the_same_frame(gpu, rtamd, oracle, earth_rgb, monkeypatch):
+    """final-scene in double precision on the caller's tree: the path kernel keeps the winning candidate as (t, leaf, side) and
+    builds the record once, after the walk, because nothing in the scene reads the (u, v) that a moving sphere or a medium inherits
+    from an earlier candidate.  Same rays and sums as with a record per accepted candidate (RTAMD_EAGER_RECORDS).  With the earth
+    map put on the moving sphere something does read that leftover: the library must notice and keep the record-per-candidate
+    kernel, whose frame is then the one the queue pipeline (one walk per ray, records as it goes) renders."""
+    from custom_scene import EditedScene
+    hs, _ = make_pair(rtamd, oracle, "final-scene", earth=earth_rgb, width=96, aspect=1.0, spp=4)
+    gpu.upload(hs)
+    _, a, sa = gpu.render(0, 4, precision=rtamd.F64, seed=31)
+    assert sa["scene_in_lds"] in (7, 8)  # a stepwise preset: nested trees spliced into the world's tree
+    monkeypatch.setenv("RTAMD_EAGER_RECORDS", "1")
+    gpu.upload(hs)
+    _, b, sb = gpu.render(0, 4, precision=rtamd.F64, seed=31)
+    monkeypatch.delenv("RTAMD_EAGER_RECORDS")
+    assert sa["rays"] == sb["rays"]
+    assert (np.abs(a - b) / (np.abs(b) + 1e-3)).max() < 1e-12
+    ed = EditedScene(rtamd, hs)
+    moving = [int(m) for m in ed.shapes["material"][ed.shapes["tag"] == 1]]
+    image_tex = [int(i) for i in np.nonzero(ed.textures["tag"] == 3)[0]]
+    assert len(moving) == 1 and len(image_tex) == 1
+    ed.materials["texture"][moving[0]] = image_tex[0]
+    gpu.upload(ed)
+    _, c, sc = gpu.render(0, 4, precision=rtamd.F64, seed=31)
+    _, d, sd = gpu.render(0, 4, precision=rtamd.F64, seed=31, pipeline=rtamd.PIPELINE_FUSED)
+    assert sc["rays"] == sd["rays"]
+    assert (np.abs(c - d) / (np.abs(d) + 1e-3)).max() < 1e-9
+    assert np.abs(c - a).max() > 1e-3  # the edit is visible: the moving sphere now shows whatever (u, v) its hits inherit
+    gpu.upload(hs)
+
+
 # Converged images: the HIP path against the CPU oracle as two INDEPENDENT Monte-Carlo estimates (different seeds), at a frame and
 # sample count the oracle can afford.  Stated tolerance: per-channel mean of linear radiance (clamped to [0,1]
 # per pixel, as color_to_rgb clamps) within 1.5 % relative, RMSE of 8x8 block means within 3 % of the image mean.
