@@ -223,7 +223,7 @@ def main():
         # per-lane walks of trees that do not fit on chip: what a closest-hit query costs on the tree THIS precision walks (the f64
         # kernels walk the reference's tree, the f32 kernels the library's own), measured on the device over the rays of 8192 paths
         walk = None
-        if rank == 0 and stats and stats[-1]["scene_in_lds"] in (4, 6, 8) and n_objects >= 100_000:
+        if rank == 0 and stats and stats[-1]["scene_in_lds"] in (4, 6, 8, 9, 10) and n_objects >= 100_000:
             walk = ctx.walk_cost(prec, n_paths=8192, seed=1)
         return {"name": name, "walk": walk, "elapsed": elapsed_max, "rays": rays, "rays_all": rays_all, "kernel_ms": kernel_ms, "launches": launches,
                 "stats": stats, "rgb": None if rgb is None else rgb.copy(), "accum": accum, "split": split, "per_rank": per_rank}
@@ -255,13 +255,14 @@ def main():
         # bytes the algorithm has to move per ray: the queue pipelines read and write one queue entry per ray; the persistent
         # pipeline keeps paths in registers and only adds finished radiance terms to the pixel sums (4 values per path)
         qb = (4 * (8 if name == "f64" else 4)) / rays_per_sample if persistent else QUEUE_BYTES_PER_RAY[name]
-        kernel = (("k_paths_stepwise" if stats[-1]["scene_in_lds"] in (5, 6, 7, 8) else "k_paths_persistent") if persistent
+        kernel = (("k_paths_stepwise" if stats[-1]["scene_in_lds"] in (5, 6, 7, 8, 9, 10) else "k_paths_persistent") if persistent
                   else ("k_bounce_fused" if args.pipeline == "fused" else "k_trace+k_shade"))
         secs = leg["kernel_ms"] * 1e-3
         valu = {"bound": "valu", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "flops_per_ray": fpr}
-        # Scenes whose tree does not fit on chip (only its top levels are staged in LDS): the walk is priced against the memory
-        # system.  Algorithmic bytes: 32 per tree node visited and per primitive tested - counted on the device, on the tree this
-        # precision's kernels walk, over the rays of a sample of the frame's paths - plus the radiance sums.
+        # Scenes whose tree does not fit on chip (presets 4, 6, 8: only its top levels are staged in LDS; 9, 10: the four-wide walk,
+        # nothing staged): the walk is priced against the memory system.  Algorithmic bytes: 32 per box tested (a four-wide node
+        # is four boxes, 128 bytes) and per primitive tested - counted on the device, on the tree this precision's kernels walk,
+        # over the rays of a sample of the frame's paths - plus the radiance sums.
         in_memory = leg["walk"] is not None
         bpr = (32.0 * (leg["walk"][0] + leg["walk"][1]) + qb) if in_memory else qb
         hbm = {"bound": "hbm", "achieved": bpr * leg["rays"] / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -187,7 +187,7 @@ typedef struct rt_stats {
   double gen_kernel_ms;        /* HIP-event time of the primary-ray kernels */
   uint64_t passes;
   uint32_t lds_bytes;          /* LDS used per workgroup by the bounce kernel */
-  uint32_t scene_in_lds;       /* kernel preset the scene selected: 0 boxes, 1 smoke, 2 spheres, 3 all (scene in LDS), 4 all (top links in LDS), 5/6 spheres-only lane walk (LDS / top links), 7/8 all without nested trees (f32 image of a scene whose nested trees were dissolved) */
+  uint32_t scene_in_lds;       /* kernel preset the scene selected: 0 boxes, 1 smoke, 2 spheres, 3 all (scene in LDS), 4 all (top links in LDS), 5/6 spheres-only lane walk (LDS / top links), 7/8 all without nested trees (images whose nested trees were dissolved or spliced), 9/10 spheres-only / all without nested trees on the four-wide form of the library's own tree */
 } rt_stats;
 
 typedef struct rt_context rt_context;
