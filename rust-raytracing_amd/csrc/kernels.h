@@ -791,7 +791,15 @@ __global__ __launch_bounds__(256) void k_first_hit(DeviceScene<R> sc, const RayI
     Stream media(seed, r.pixel, r.sample, r.bounce, STAGE_MEDIA);
     Rec<R> rec;
     Visits tally;
-    bool h = closest_hit<R, CU>(sv, sc.root_link, ray, (R)r.tmin, (R)r.tmax, rec, media, Origin(), MODE == 2 ? &tally : nullptr);
+    bool h;
+    if constexpr (MODE == 0 && sizeof(R) == 8 && C::walk == WALK_LANE_WIDE) {
+      // The plain query in double precision reports the record the reference's walk leaves behind, leftover (u, v) of a moving
+      // sphere included, and those depend on the order of the tests: it walks the list, which every image carries and which keeps
+      // the tree's own order.  The render kernels' walk is what the as-rendered query shows.
+      h = traverse_lane<R, CU, 0>(sv, sc.root_link, ray, (R)r.tmin, (R)r.tmax, rec, media, Origin(), 0u, nullptr);
+    } else {
+      h = closest_hit<R, CU>(sv, sc.root_link, ray, (R)r.tmin, (R)r.tmax, rec, media, Origin(), MODE == 2 ? &tally : nullptr);
+    }
     HitIO o;
     o.hit = h ? 1 : 0;
     if (h) {

@@ -529,6 +529,17 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   std::vector<int> sub_root64((size_t)s->n_objects, LINK_END);
   int preset64 = preset;
   const bool relinked = spliced_any || skipped_any;
+  // Scenes of spheres only: the caller's tree in its four-wide form as well (see wide_from_links), which the double-precision
+  // image takes when it does not fit in LDS.  RTAMD_NO_WIDE=1 / RTAMD_F64_LIST=1 keep the list.
+  std::vector<WideTmp> wide64;
+  const bool want_wide64 = preset == PRESET_BALLS_LDS && !std::getenv("RTAMD_NO_WIDE") && !std::getenv("RTAMD_F64_LIST");
+  auto fold64 = [&](const std::vector<TmpLink>& list, int list_root) {
+    if (!want_wide64) return;
+    const int need = wide_from_links(list, list_root, wide64);
+    if (need > (int)kWideStack) wide64.clear();
+    if (timing) std::fprintf(stderr, "rt_upload_scene: caller's tree four-wide: %zu nodes, stack need %d (limit %u)\n", wide64.size(), need, kWideStack);
+  };
+  if (!relinked) fold64(lb.links, root);
   if (relinked) {
     LinkBuilder lbs(scene64);
     lbs.splice = &splice;
@@ -538,6 +549,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     for (int i = 0; i < s->n_objects && lbs.err.empty(); ++i)
       if ((s->objects[i].flags & RT_OBJ_SUB_BVH) && !splice[(size_t)i]) sub_root64[(size_t)i] = lbs.node(s->objects[i].geom, LINK_END, 0, tree64++);
     if (!lbs.err.empty()) return fail(RT_E_INVALID, "rt_upload_scene: " + lbs.err);
+    fold64(lbs.links, root64);
     links64 = reorder(lbs.links, root64, sub_root64);
     if (has_nested && !nested_left64 && preset == PRESET_ALL_LDS) preset64 = PRESET_FLATALL_LDS;
     mark("f64 list: nested trees spliced, copies left out");
@@ -583,8 +595,8 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   const int device = c->device;
   std::thread t_sd([&] {
     if (hipSetDevice(device) != hipSuccess) { rc_sd = RT_E_HIP; err_sd = "hipSetDevice failed"; return; }
-    rc_sd = relinked ? build_image<double>(c, scene64, links64, root64, sub_root64, preset64, c->sd, nullptr)
-                        : build_image<double>(c, *s, links, root, sub_root, preset, c->sd, nullptr);
+    rc_sd = relinked ? build_image<double>(c, scene64, links64, root64, sub_root64, preset64, c->sd, &wide64)
+                        : build_image<double>(c, *s, links, root, sub_root, preset, c->sd, &wide64);
     if (rc_sd != RT_OK) err_sd = g_err;
   });
   // RT_F64_OWN_TREE: the library's tree once more, in double

@@ -305,6 +305,36 @@ def test_wide_walk_and_list_walk_agree(gpu, rtamd, oracle, earth_rgb, name, kw, 
             assert np.abs(a["n"][both] - b["n"][both]).max() < 1e-4
 
 
+@pytest.mark.parametrize("name,kw", [("random", {}), ("mega-spheres", {"mega_grid": 60, "width": 160, "spp": 4})])
+def test_f64_wide_walk_of_the_callers_tree_is_exact(gpu, rtamd, oracle, earth_rgb, name, kw, monkeypatch):
+    """Scenes of spheres only: the default double-precision image walks the caller's tree - the reference's nodes, boxes and leaves,
+    exact copies left out - folded four boxes to a node, nearest child first, instead of as a list in the reference's order.  No two
+    different spheres lie at the same distance along a ray, so the order of the tests decides nothing: ids, t, p and the normal of
+    100 000 rays and a small frame's ray count and sums must equal the list walk's (RTAMD_F64_LIST) bit for bit - the other tests
+    hold this same image to the oracle."""
+    hs, _ = make_pair(rtamd, oracle, name, earth=earth_rgb, **kw)
+    rng = np.random.default_rng(8642)
+    lo, hi = SCENE_BOXES.get(name, ((-60, 0.05, -60), (60, 3, 60)))
+    rays = random_rays(rng, 100_000, lo, hi)
+    gpu.upload(hs)
+    a = gpu.trace_batch(rays, precision=rtamd.F64, seed=3, as_rendered=True)
+    a0 = gpu.trace_batch(rays, precision=rtamd.F64, seed=3)
+    _, fa, sa = gpu.render(0, 2, precision=rtamd.F64, seed=3)
+    monkeypatch.setenv("RTAMD_F64_LIST", "1")
+    gpu.upload(hs)
+    b = gpu.trace_batch(rays, precision=rtamd.F64, seed=3, as_rendered=True)
+    b0 = gpu.trace_batch(rays, precision=rtamd.F64, seed=3)
+    _, fb, sb = gpu.render(0, 2, precision=rtamd.F64, seed=3)
+    monkeypatch.delenv("RTAMD_F64_LIST")
+    gpu.upload(hs)
+    assert sa["scene_in_lds"] == 9 and sb["scene_in_lds"] in (5, 6), (sa["scene_in_lds"], sb["scene_in_lds"])
+    for f in ID_FIELDS + ("t", "p", "n"):
+        assert np.array_equal(a[f], b[f]), (name, f)
+    assert a0.tobytes() == b0.tobytes()  # the plain query walks the list in either image (leftover (u, v) included)
+    assert sa["rays"] == sb["rays"]
+    assert (np.abs(fa - fb) / (np.abs(fb) + 1e-3)).max() < 1e-12
+
+
 @pytest.mark.parametrize("name,mega_grid", [("random", 0), ("final-scene", 0), ("mega-spheres", 40), ("cornell-box", 0)])
 def test_f64_on_the_librarys_own_tree(gpu, rtamd, oracle, earth_rgb, name, mega_grid):
     """RT_F64_OWN_TREE: double arithmetic on the tree the library builds for itself.  Checked against the ORACLE like the default
@@ -366,7 +396,7 @@ def test_f64_list_variants_agree(gpu, rtamd, oracle, earth_rgb, name, switch, mo
     for f in ID_FIELDS + ("t", "p", "n"):
         assert np.array_equal(a[f], b[f]), (name, switch, f)
     sa = gpu.render_accum(None, 0, 1, precision=rtamd.F64, seed=3)
-    assert sa["scene_in_lds"] in (5, 6, 7, 8), sa["scene_in_lds"]  # by default neither scene takes a nested-tree preset
+    assert sa["scene_in_lds"] in (5, 6, 7, 8, 9), sa["scene_in_lds"]  # by default neither scene takes a nested-tree preset
 
 
 
