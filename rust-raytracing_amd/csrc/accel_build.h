@@ -163,6 +163,13 @@ class FastTreeBuilder {
     }
     return g;  // 26 values at most; the rest stays zero
   }
+  // The padded box of a bare shape as the library's own tree uses it (no ray whose shape test succeeds misses it), false for
+  // objects it has no such box for: nested trees, and spheres of negative radius, whose reach the reference's boxes decide.
+  bool tight_box(int o, Box3d& out) const {
+    if ((s_.objects[o].flags & RT_OBJ_SUB_BVH) || has_guard(o)) return false;
+    out = object_box(o);
+    return true;
+  }
   // Objects that may stand in for an exact copy of themselves: bare or wrapped shapes, but no medium (it draws random numbers per
   // visit), no nested tree, and no sphere of negative radius (what reaches it is decided by the boxes around each copy).
   bool copy_eligible(int o) const {
@@ -227,9 +234,11 @@ class FastTreeBuilder {
     Box3d b;
     switch (sh.tag) {
       case RT_SHAPE_SPHERE: return sphere_box(sh.p, sh.p[3]);
-      case RT_SHAPE_MOVING_SPHERE: {  // centre0 p[0..2], centre1 p[3..5], radius p[6], time0 p[7], time1 p[8]; rays have time in [0, 1)
+      case RT_SHAPE_MOVING_SPHERE: {  // centre0 p[0..2], centre1 p[3..5], radius p[6], time0 p[7], time1 p[8]
         b.reset();
-        for (double time : {0.0, 1.0}) {
+        // linear motion: the extremes of the time a ray can carry - the camera's shutter interval, and 0, which RotateY gives its
+        // local ray (src/hittable.rs:214-223)
+        for (double time : {std::min(0.0, s_.camera.shutter_open_time), std::max(1.0, s_.camera.shutter_close_time)}) {
           double f = (time - sh.p[7]) / (sh.p[8] - sh.p[7]);
           double c[3] = {sh.p[0] + f * (sh.p[3] - sh.p[0]), sh.p[1] + f * (sh.p[4] - sh.p[1]), sh.p[2] + f * (sh.p[5] - sh.p[2])};
           b.grow(sphere_box(c, sh.p[6]));
@@ -550,11 +559,12 @@ class FastTreeBuilder {
 // reference's nodes, boxes and order, exact copies left out).  A node of the list with its box becomes a slot of a wide node; a
 // leaf takes the box of the list entry above it, which is the last box the list walk tests before it reaches the leaf, and the
 // boxes of the entries folded away in between contain those below them, so a leaf is tested by exactly the rays whose list walk
-// could accept it: those that pass every box above it with a distance below the closest hit so far.  What the wide walk changes
+// could accept it: those that pass every box above it with a distance below the closest hit so far (`tight`: and that pass the
+// shape's own padded box, which every ray does whose shape test can succeed).  What the wide walk changes
 // is the order of the tests, which decides nothing but exact ties - so this form is only built for scenes of spheres, where two
 // different surfaces never lie at the same distance along a ray (exact copies are reduced to the one the reference reports).
 // Returns the stack entries the deepest walk can hold.
-inline int wide_from_links(const std::vector<TmpLink>& links, int root, std::vector<WideTmp>& wide) {
+inline int wide_from_links(const std::vector<TmpLink>& links, int root, std::vector<WideTmp>& wide, const FastTreeBuilder* tight = nullptr) {
   wide.clear();
   if (root < 0 || (links[(size_t)root].hit & LEAF_FLAG)) return 0;
   struct Item { int entry; int box_of; int level; };  // a list entry, the inner entry whose box it is tested with (itself when it is one), levels below the wide node
@@ -604,6 +614,18 @@ inline int wide_from_links(const std::vector<TmpLink>& links, int root, std::vec
       const TmpLink& e = links[(size_t)items[j].entry];
       if (e.hit & LEAF_FLAG) {
         w.child[j] = e.hit;
+        // ... cut down to the shape's own padded box where the two overlap: a ray outside that box fails the shape's test anyway
+        Box3d own;
+        if (tight && tight->tight_box((int)(e.hit & LEAF_INDEX_MASK), own)) {
+          double lo[3], hi[3];
+          bool overlap = true;
+          for (int a = 0; a < 3; ++a) {
+            lo[a] = std::max(w.lo[j][a], own.mn[a]); hi[a] = std::min(w.hi[j][a], own.mx[a]);
+            overlap = overlap && lo[a] <= hi[a];
+          }
+          if (overlap)
+            for (int a = 0; a < 3; ++a) { w.lo[j][a] = lo[a]; w.hi[j][a] = hi[a]; }
+        }
       } else {
         w.child[j] = (uint32_t)wide.size();
         wide.emplace_back();

@@ -535,7 +535,8 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   const bool want_wide64 = preset == PRESET_BALLS_LDS && !std::getenv("RTAMD_NO_WIDE") && !std::getenv("RTAMD_F64_LIST");
   auto fold64 = [&](const std::vector<TmpLink>& list, int list_root) {
     if (!want_wide64) return;
-    const int need = wide_from_links(list, list_root, wide64);
+    const FastTreeBuilder shapes_of(*s);  // sphere scenes have no nested trees: the caller's objects as they are
+    const int need = wide_from_links(list, list_root, wide64, &shapes_of);
     if (need > (int)kWideStack) wide64.clear();
     if (timing) std::fprintf(stderr, "rt_upload_scene: caller's tree four-wide: %zu nodes, stack need %d (limit %u)\n", wide64.size(), need, kWideStack);
   };
