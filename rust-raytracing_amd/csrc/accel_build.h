@@ -560,7 +560,7 @@ class FastTreeBuilder {
 // leaf takes the box of the list entry above it, which is the last box the list walk tests before it reaches the leaf, and the
 // boxes of the entries folded away in between contain those below them, so a leaf is tested by exactly the rays whose list walk
 // could accept it: those that pass every box above it with a distance below the closest hit so far (`tight`: and that pass the
-// shape's own padded box, which every ray does whose shape test can succeed).  What the wide walk changes
+// padded boxes of the shapes themselves, which every ray does whose shape test can succeed).  What the wide walk changes
 // is the order of the tests, which decides nothing but exact ties - so this form is only built for scenes of spheres, where two
 // different surfaces never lie at the same distance along a ray (exact copies are reduced to the one the reference reports).
 // Returns the stack entries the deepest walk can hold.
@@ -578,6 +578,30 @@ inline int wide_from_links(const std::vector<TmpLink>& links, int root, std::vec
     const double d[3] = {l.bmax[0] - l.bmin[0], l.bmax[1] - l.bmin[1], l.bmax[2] - l.bmin[2]};
     return (d[0] < 0 || d[1] < 0 || d[2] < 0) ? 0.0 : 2.0 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
   };
+  // What the shapes below an entry can occupy: the union of their padded boxes (everything, when a shape below has none).  A ray
+  // that misses it fails every shape test below the entry, so the entry's box may be cut down to the overlap of the two - the
+  // reference's boxes are wider than that wherever a copy that is no longer walked, or a loose median split, stretched them.
+  const double inf = std::numeric_limits<double>::infinity();
+  std::vector<Box3d> reach;
+  if (tight) {
+    reach.resize(links.size());
+    std::vector<Item> below;
+    for (size_t i = links.size(); i-- > 0;) {  // children come after their parent in the list as it is built
+      Box3d& r = reach[i];
+      if (links[i].hit & LEAF_FLAG) {
+        if (!tight->tight_box((int)(links[i].hit & LEAF_INDEX_MASK), r))
+          for (int a = 0; a < 3; ++a) { r.mn[a] = -inf; r.mx[a] = inf; }
+        continue;
+      }
+      r.reset();
+      below.clear();
+      children((int)i, 0, below);
+      for (const Item& c : below) {
+        if (c.entry <= (int)i) { for (int a = 0; a < 3; ++a) { r.mn[a] = -inf; r.mx[a] = inf; } break; }  // not the order assumed: no cut
+        r.grow(reach[(size_t)c.entry]);
+      }
+    }
+  }
   wide.emplace_back();
   std::vector<int> queue{root};
   std::vector<Item> items, grown;
@@ -612,20 +636,19 @@ inline int wide_from_links(const std::vector<TmpLink>& links, int root, std::vec
       const TmpLink& b = links[(size_t)items[j].box_of];
       for (int a = 0; a < 3; ++a) { w.lo[j][a] = b.bmin[a]; w.hi[j][a] = b.bmax[a]; }
       const TmpLink& e = links[(size_t)items[j].entry];
+      if (tight) {  // ... cut down to what the shapes below can occupy, where the two overlap
+        const Box3d& own = reach[(size_t)items[j].entry];
+        double lo[3], hi[3];
+        bool overlap = true;
+        for (int a = 0; a < 3; ++a) {
+          lo[a] = std::max(w.lo[j][a], own.mn[a]); hi[a] = std::min(w.hi[j][a], own.mx[a]);
+          overlap = overlap && lo[a] <= hi[a];
+        }
+        if (overlap)
+          for (int a = 0; a < 3; ++a) { w.lo[j][a] = lo[a]; w.hi[j][a] = hi[a]; }
+      }
       if (e.hit & LEAF_FLAG) {
         w.child[j] = e.hit;
-        // ... cut down to the shape's own padded box where the two overlap: a ray outside that box fails the shape's test anyway
-        Box3d own;
-        if (tight && tight->tight_box((int)(e.hit & LEAF_INDEX_MASK), own)) {
-          double lo[3], hi[3];
-          bool overlap = true;
-          for (int a = 0; a < 3; ++a) {
-            lo[a] = std::max(w.lo[j][a], own.mn[a]); hi[a] = std::min(w.hi[j][a], own.mx[a]);
-            overlap = overlap && lo[a] <= hi[a];
-          }
-          if (overlap)
-            for (int a = 0; a < 3; ++a) { w.lo[j][a] = lo[a]; w.hi[j][a] = hi[a]; }
-        }
       } else {
         w.child[j] = (uint32_t)wide.size();
         wide.emplace_back();
