@@ -457,6 +457,7 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? (sizeof(R) == 8 ? RT_NESTED
 #define RT_STEP_THREADS 256
 #endif
 constexpr uint32_t kStepThreads = RT_STEP_THREADS;
+static_assert(RT_STEP_THREADS <= 256, "the four-wide presets size their LDS stacks for workgroups of four waves (lds_bytes_for)");
 #ifndef RT_RESTART_LANES
 #define RT_RESTART_LANES 32
 #define RT_BOX_STEPS 4

@@ -82,8 +82,18 @@ def main():
         shutil.copy(f, os.path.join(dst, tag + suffix + "_kernel_stats.csv"))
     if os.path.exists(os.path.join(src, "bench_line.json")):
         shutil.copy(os.path.join(src, "bench_line.json"), os.path.join(dst, tag + suffix + "_bench_line.json"))
-    for prec in ("f64", "f32"):
-        digest(tag, prec, scene, spp, src, dst)
+    out = {prec: digest(tag, prec, scene, spp, src, dst) for prec in ("f64", "f32")}
+    # the bench line of the trace run read roofline.traffic from the digest of an EARLIER profile: bring it to this one's counters
+    # (same frame, same sample count, one launch per step)
+    line_path = os.path.join(dst, tag + suffix + "_bench_line.json")
+    if os.path.exists(line_path):
+        with open(line_path) as f:
+            line = json.loads(f.read())
+        for prec, leg in (("f64", line), ("f32", line.get("f32") or {})):
+            if out[prec] and isinstance(leg.get("roofline"), dict) and leg.get("dtype", prec) == prec:
+                leg["roofline"]["traffic"] = out[prec]["hbm_bytes_per_frame"]["total"]
+        with open(line_path, "w") as f:
+            f.write(json.dumps(line) + "\n")
 
 
 if __name__ == "__main__":
