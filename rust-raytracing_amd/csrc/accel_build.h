@@ -45,6 +45,10 @@ class FastTreeBuilder {
   // left (every one was dissolved).  `wide_stack_need`: entries the deepest walk can have on its stack.
   std::vector<WideTmp> wide;
   int wide_stack_need = 0;
+  // Leaves left out of the four-wide form: objects as large as the scene (a fog that fills it, the ground sphere).  Nearly every
+  // ray has to test them, and inside the tree each lane would reach them at a moment of its own; the walk tests them first, for
+  // all its lanes at once (DeviceScene::pre), which also gives it a first `closest` to prune with.  Leaf words, at most kWidePre.
+  std::vector<uint32_t> wide_pre;
 
   // `ref` are the links of the reference trees before reordering, `ref_root` / `ref_sub_root` their roots.
   // Fills `links` (top-level tree first, then the nested ones), `root` and `sub_root`.
@@ -377,12 +381,25 @@ class FastTreeBuilder {
   void wide_items(const std::vector<Node>& nodes, int n, std::vector<WideItem>& out) const {
     const Node& nd = nodes[(size_t)n];
     if (nd.obj < 0) { out.push_back(WideItem{nd.box, n, 0u}); return; }
+    for (uint32_t word : wide_pre)
+      if ((int)(word & LEAF_INDEX_MASK) == nd.obj) return;  // tested ahead of the walk
     const Box3d b = has_guard(nd.obj) ? guard_box(nd.obj) : nd.box;
     out.push_back(WideItem{b, -1, leaf_word(nd.obj)});
     if (!twice_.empty() && twice_[(size_t)nd.obj]) out.push_back(WideItem{b, -1, leaf_word(nd.obj) | LEAF_SECOND});
   }
   void build_wide(const std::vector<Node>& nodes) {
     wide.clear();
+    wide_pre.clear();
+    if (!std::getenv("RTAMD_NO_PRE_LEAVES") && nodes.size() > 16) {
+      const double whole = nodes[0].box.area();
+      for (const Node& nd : nodes) {
+        if (nd.obj < 0 || has_guard(nd.obj) || !(nd.box.area() >= 0.5 * whole)) continue;
+        const bool twice = !twice_.empty() && twice_[(size_t)nd.obj];
+        if (wide_pre.size() + (twice ? 2u : 1u) > kWidePre) break;
+        wide_pre.push_back(leaf_word(nd.obj));
+        if (twice) wide_pre.push_back(leaf_word(nd.obj) | LEAF_SECOND);
+      }
+    }
     wide.emplace_back();
     std::vector<int> queue{0};  // binary node of wide node k
     std::vector<WideItem> items, grown;

@@ -147,7 +147,7 @@ inline uint32_t grid_for(const rt_context* c, uint64_t n, uint32_t blocks_per_cu
 template <class R> void layout_sections(rtd::BlobLayout& lay);
 template <class R>
 int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink>& links, int root_link, const std::vector<int>& sub_root_of_object,
-                int preset, SceneImage<R>& im, const std::vector<WideTmp>* wide);
+                int preset, SceneImage<R>& im, const std::vector<WideTmp>* wide, const std::vector<uint32_t>* pre);
 template <class R>
 int render_accum_impl(rt_context* c, const rt_render_params& p, void* accum_dev, rt_stats* stats, unsigned long long* counters_override = nullptr,
                       unsigned long long* host_rays = nullptr);

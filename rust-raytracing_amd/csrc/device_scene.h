@@ -61,6 +61,7 @@ struct alignas(128) WideNode {
 #define RT_WIDE_STACK 36
 #endif
 constexpr uint32_t kWideStack = RT_WIDE_STACK;
+constexpr uint32_t kWidePre = 4;  // leaves a four-wide image may keep outside its tree (DeviceScene::pre)
 constexpr uint32_t kWideStackBytesPerWave = kWideStack * 64u * 4u;
 
 // tags equal the RT_SHAPE_* / RT_MAT_* / RT_TEX_* / RT_OBJ_* values of rtamd.h
@@ -142,6 +143,8 @@ template <class R> struct DeviceScene {
   int32_t n_images;
   int32_t root_link;
   uint32_t lds_links;  // number of leading links staged in LDS when the blob is not staged whole
+  uint32_t n_pre;      // four-wide walk: leaves tested ahead of the walk (objects as large as the scene), leaf words in `pre`
+  uint32_t pre[4];
   uint32_t defer_ok;   // no texture of the scene reads the (u, v) a moving sphere or a medium inherits from an earlier candidate
   DCamera<R> camera;
   DBackground<R> background;
@@ -298,6 +301,7 @@ template <class R, class C> struct SceneView {
   const CameraRecord<R>* camera_rec;  // global memory, scalar loads
   const WideNode* wide;               // WALK_LANE_WIDE: the four-wide tree (global memory)
   uint32_t* stack;                    // ... and the stacks of the lane's wave in LDS: child words, [entry][lane]
+  uint32_t n_pre, pre[4];             // ... and the leaves tested ahead of the walk
 
   RT_DEV DCamera<R> camera() const { return camera_of(load_uniform(camera_rec)); }
   RT_DEV static DCamera<R> camera_of(const CameraRecord<R>& r) {
@@ -370,6 +374,8 @@ template <class R, class C> RT_DEV SceneView<R, C> make_view(const DeviceScene<R
   }
   __syncthreads();
   v.wide = reinterpret_cast<const WideNode*>(g + sc.lay.wide_off);
+  v.n_pre = sc.n_pre;
+  for (int k = 0; k < 4; ++k) v.pre[k] = sc.pre[k];
   v.stack = reinterpret_cast<uint32_t*>(lds + (threadIdx.x >> 6) * kWideStackBytesPerWave);
   v.n_links = sc.lay.n_links;
   v.links = reinterpret_cast<const BoxLink*>(geom + sc.lay.links_off);

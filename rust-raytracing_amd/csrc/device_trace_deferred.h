@@ -673,24 +673,28 @@ RT_DEV bool traverse_wide(const SceneView<R, C>& sv, const Ray<R>& ray, R t_min,
   R closest = t_max;
   bool any = false;
   int best_leaf = -1, best_side = -1;
-  while (!w.idle()) {
-    while (w.at_box()) {
-      if (tally) tally->boxes += 4;  // four boxes, one 128-byte record
-      w.box_step(sv.wide, sv.stack, box, ray, t_min, closest);
-    }
-    if (w.idle()) break;
+  auto test_leaf = [&](uint32_t word) {
     if (tally) ++tally->leaves;
     if constexpr (DEFER) {
       RayInv<R> ri(ray.d);
       ri.inv = box.inv;
       R t;
       int side;
-      if (leaf_t<R, C>(sv, w.cur, ray, ri, t_min, closest, media, org, t, side, visit_bit(w.cur, 0))) {
-        closest = t; best_leaf = (int)(w.cur & LEAF_INDEX_MASK); best_side = side;
+      if (leaf_t<R, C>(sv, word, ray, ri, t_min, closest, media, org, t, side, visit_bit(word, 0))) {
+        closest = t; best_leaf = (int)(word & LEAF_INDEX_MASK); best_side = side;
       }
     } else {
-      if (leaf_hit<R, C, 0>(sv, w.cur, ray, t_min, closest, rec, media, org)) { closest = rec.t; any = true; }
+      if (leaf_hit<R, C, 0>(sv, word, ray, t_min, closest, rec, media, org)) { closest = rec.t; any = true; }
     }
+  };
+  for (uint32_t k = 0; k < sv.n_pre; ++k) test_leaf(sv.pre[k]);  // objects as large as the scene, kept outside the tree
+  while (!w.idle()) {
+    while (w.at_box()) {
+      if (tally) tally->boxes += 4;  // four boxes, one 128-byte record
+      w.box_step(sv.wide, sv.stack, box, ray, t_min, closest);
+    }
+    if (w.idle()) break;
+    test_leaf(w.cur);
     w.pop(sv.stack);
   }
   if constexpr (DEFER) {

@@ -467,6 +467,10 @@ static_assert(RT_STEP_THREADS <= 256, "the four-wide presets size their LDS stac
 #define RT_LEAF_LANES 16
 #endif
 constexpr uint32_t kLeafLanes = RT_LEAF_LANES;
+#ifndef RT_LEAF_LANES_COSTLY
+#define RT_LEAF_LANES_COSTLY 24
+#endif
+constexpr uint32_t kLeafLanesCostly = RT_LEAF_LANES_COSTLY;
 constexpr uint32_t kRestartLanes = RT_RESTART_LANES;
 constexpr int kBoxStepsPerTurn = RT_BOX_STEPS;
 constexpr int kTurnsPerCheck = RT_TURNS;
@@ -497,6 +501,8 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
   // on the caller's tree fills the record at every accepted candidate, as the reference does (a hit that writes no (u, v) must find
   // the ones an earlier candidate left), unless the launcher knows that nothing reads such a leftover (DEFER_LIST).
   constexpr bool DEFER = C::template defer_records<R>() || (DEFER_LIST && C::costly_records());
+  // presets with boxes, wrappers or media have the longer leaf code and wait for more lanes before they run it (final-scene +2-3 %)
+  constexpr uint32_t leaf_threshold = C::costly_records() ? kLeafLanesCostly : kLeafLanes;
   int best_leaf = -1, best_side = -1;
   R closest = Lim<R>::inf();
   bool any = false;
@@ -575,6 +581,10 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
         any = false;
         best_leaf = -1;
         rec = Rec<R>();  // a fresh HitRecord per world.hit call (src/render.rs:157)
+        if constexpr (WIDE) {  // objects as large as the scene, kept outside the tree: all starting lanes test them together
+          Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
+          for (uint32_t k = 0; k < sc.n_pre; ++k) step_leaf(sc.pre[k], media);
+        }
       }
       if (__ballot(i >= 0 || resume != 0u) == 0ull) break;  // no walk in progress, no draw unfinished, no path left to start
     }
@@ -593,7 +603,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
         RT_STAMP(1);
         const bool at_leaf = wl.at_leaf();
         const unsigned long long leaf_lanes = __ballot(at_leaf);
-        if ((uint32_t)__popcll(leaf_lanes) < kLeafLanes && __ballot(wl.at_box()) != 0ull) continue;
+        if ((uint32_t)__popcll(leaf_lanes) < leaf_threshold && __ballot(wl.at_box()) != 0ull) continue;
         RT_STAMP_COUNT(5, __popcll(leaf_lanes));
         RT_STAMP_COUNT(6, 1);
         if (at_leaf) {
@@ -624,7 +634,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES
       RT_STAMP(1);
       const bool at_leaf = i >= 0 && (lk.hit & LEAF_FLAG);
       const unsigned long long leaf_lanes = __ballot(at_leaf);
-      if ((uint32_t)__popcll(leaf_lanes) < kLeafLanes && __ballot(i >= 0 && !(lk.hit & LEAF_FLAG)) != 0ull) continue;
+      if ((uint32_t)__popcll(leaf_lanes) < leaf_threshold && __ballot(i >= 0 && !(lk.hit & LEAF_FLAG)) != 0ull) continue;
       RT_STAMP_COUNT(5, __popcll(leaf_lanes));
       RT_STAMP_COUNT(6, 1);
       if (at_leaf) {

@@ -65,7 +65,7 @@ template <class R> void layout_sections(BlobLayout& lay) {
 
 template <class R>
 int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink>& links, int root_link, const std::vector<int>& sub_root_of_object,
-                int preset, SceneImage<R>& im, const std::vector<WideTmp>* wide) {
+                int preset, SceneImage<R>& im, const std::vector<WideTmp>* wide, const std::vector<uint32_t>* pre) {
   BlobLayout lay{};
   lay.n_links = (uint32_t)links.size();
   lay.n_objects = (uint32_t)s.n_objects;
@@ -267,6 +267,13 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
   d.n_images = s.n_images;
   d.root_link = root_link;
   d.defer_ok = (reads_leftover_uv(s) || getenv("RTAMD_EAGER_RECORDS")) ? 0u : 1u;
+  d.n_pre = 0;
+  if (lay.n_wide && pre)
+    for (uint32_t word : *pre) {
+      if (d.n_pre >= kWidePre) return fail(RT_E_INVALID, "internal error: too many leaves kept outside the four-wide tree");
+      // see the links above: a re-centred sphere's front_face rule is read from the object's flags
+      d.pre[d.n_pre++] = (!single && (s.objects[word & LEAF_INDEX_MASK].flags & OBJ_FRONT_CHAIN)) ? (word & ~LEAF_SIMPLE) : word;
+    }
   uint32_t top_bytes = kLdsTopMax;
   if (const char* e = getenv("RTAMD_TOP_LDS_BYTES")) top_bytes = (uint32_t)std::max(0, atoi(e));  // measurement switch
   d.lds_links = (preset == PRESET_ALL_TOP || preset == PRESET_BALLS_TOP || preset == PRESET_FLATALL_TOP) ? std::min<uint32_t>(lay.n_links, top_bytes / (uint32_t)sizeof(BoxLink)) : 0u;
@@ -580,7 +587,7 @@ template <class R> int resolve_impl(rt_context* c, const void* accum_dev, size_t
 #define RTI_INSTANTIATE(R)                                                                                                                   \
   template void layout_sections<R>(BlobLayout&);                                                                                        \
   template int build_image<R>(rt_context*, const rt_scene_desc&, const std::vector<TmpLink>&, int, const std::vector<int>&, int, SceneImage<R>&, \
-                              const std::vector<WideTmp>*);                                                                              \
+                              const std::vector<WideTmp>*, const std::vector<uint32_t>*);                                                \
   template int render_accum_impl<R>(rt_context*, const rt_render_params&, void*, rt_stats*, unsigned long long*, unsigned long long*);                                              \
   template int trace_batch_impl<R>(rt_context*, const rt_ray*, size_t, rt_hit*, uint64_t, int);                                                   \
   template int pairs_kernel_impl<R>(rt_context*, int, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint32_t*, size_t, uint64_t, void*, \

@@ -562,10 +562,11 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   mark("preset, nested trees");
   // the own tree's four-wide form, handed to the images that walk the own tree when its walk's stack fits (device_scene.h: kWideStack)
   std::vector<WideTmp> wide_nodes;
+  std::vector<uint32_t> wide_pre;  // leaves that image keeps outside the tree (FastTreeBuilder::wide_pre)
   if (own_tree) {
     FastTreeBuilder ftb(scene32);
     ftb.build(lb.links, root, sub_root, dissolved, fast_links, fast_root, fast_sub_root);
-    if (!ftb.wide.empty() && ftb.wide_stack_need <= (int)kWideStack) wide_nodes.swap(ftb.wide);
+    if (!ftb.wide.empty() && ftb.wide_stack_need <= (int)kWideStack) { wide_nodes.swap(ftb.wide); wide_pre.swap(ftb.wide_pre); }
     if (timing) std::fprintf(stderr, "rt_upload_scene: four-wide tree of %zu nodes, stack need %d (limit %u)\n", wide_nodes.size(), ftb.wide_stack_need, kWideStack);
     mark("own tree");
     fast_links = reorder(fast_links, fast_root, fast_sub_root);
@@ -596,19 +597,19 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   const int device = c->device;
   std::thread t_sd([&] {
     if (hipSetDevice(device) != hipSuccess) { rc_sd = RT_E_HIP; err_sd = "hipSetDevice failed"; return; }
-    rc_sd = relinked ? build_image<double>(c, scene64, links64, root64, sub_root64, preset64, c->sd, &wide64)
-                        : build_image<double>(c, *s, links, root, sub_root, preset, c->sd, &wide64);
+    rc_sd = relinked ? build_image<double>(c, scene64, links64, root64, sub_root64, preset64, c->sd, &wide64, nullptr)
+                        : build_image<double>(c, *s, links, root, sub_root, preset, c->sd, &wide64, nullptr);
     if (rc_sd != RT_OK) err_sd = g_err;
   });
   // RT_F64_OWN_TREE: the library's tree once more, in double
   std::thread t_own([&] {
     if (!want_own64) return;
     if (hipSetDevice(device) != hipSuccess) { rc_own = RT_E_HIP; err_own = "hipSetDevice failed"; return; }
-    rc_own = build_image<double>(c, scene32, fast_links, fast_root, fast_sub_root, preset32, c->sd_own, &wide_nodes);
+    rc_own = build_image<double>(c, scene32, fast_links, fast_root, fast_sub_root, preset32, c->sd_own, &wide_nodes, &wide_pre);
     if (rc_own != RT_OK) err_own = g_err;
   });
-  rc = own_tree ? build_image<float>(c, scene32, fast_links, fast_root, fast_sub_root, preset32, c->sf, &wide_nodes)
-                : build_image<float>(c, *s, links, root, sub_root, preset, c->sf, nullptr);
+  rc = own_tree ? build_image<float>(c, scene32, fast_links, fast_root, fast_sub_root, preset32, c->sf, &wide_nodes, &wide_pre)
+                : build_image<float>(c, *s, links, root, sub_root, preset, c->sf, nullptr, nullptr);
   t_sd.join();
   t_own.join();
   if (rc == RT_OK && rc_sd != RT_OK) rc = fail(rc_sd, err_sd);
