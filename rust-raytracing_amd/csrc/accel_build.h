@@ -581,14 +581,31 @@ class FastTreeBuilder {
 // is the order of the tests, which decides nothing but exact ties - so this form is only built for scenes of spheres, where two
 // different surfaces never lie at the same distance along a ray (exact copies are reduced to the one the reference reports).
 // Returns the stack entries the deepest walk can hold.
-inline int wide_from_links(const std::vector<TmpLink>& links, int root, std::vector<WideTmp>& wide, const FastTreeBuilder* tight = nullptr) {
+inline int wide_from_links(const std::vector<TmpLink>& links, int root, std::vector<WideTmp>& wide, const FastTreeBuilder* tight = nullptr,
+                           std::vector<uint32_t>* pre = nullptr) {
   wide.clear();
+  if (pre) pre->clear();
   if (root < 0 || (links[(size_t)root].hit & LEAF_FLAG)) return 0;
+  // `pre`: shapes as large as the scene leave the tree and are tested ahead of the walk (FastTreeBuilder::wide_pre), which the
+  // caller may only ask for where the order of the tests decides nothing
+  if (pre && tight && links.size() > 16 && !std::getenv("RTAMD_NO_PRE_LEAVES")) {
+    Box3d all, own;
+    all.reset();
+    for (const TmpLink& l : links)
+      if ((l.hit & LEAF_FLAG) && tight->tight_box((int)(l.hit & LEAF_INDEX_MASK), own)) all.grow(own);
+    for (const TmpLink& l : links)
+      if ((l.hit & LEAF_FLAG) && pre->size() < kWidePre && tight->tight_box((int)(l.hit & LEAF_INDEX_MASK), own) && own.area() >= 0.5 * all.area() &&
+          std::find(pre->begin(), pre->end(), l.hit) == pre->end())
+        pre->push_back(l.hit);
+  }
+  auto is_pre = [&](uint32_t word) { return pre && std::find(pre->begin(), pre->end(), word) != pre->end(); };
   struct Item { int entry; int box_of; int level; };  // a list entry, the inner entry whose box it is tested with (itself when it is one), levels below the wide node
   auto children = [&](int i, int level, std::vector<Item>& out) {
     const TmpLink& l = links[(size_t)i];
-    for (int c = (int)l.hit; c != l.miss && c != i && c >= 0; c = links[(size_t)c].miss)
+    for (int c = (int)l.hit; c != l.miss && c != i && c >= 0; c = links[(size_t)c].miss) {
+      if ((links[(size_t)c].hit & LEAF_FLAG) && is_pre(links[(size_t)c].hit)) continue;
       out.push_back(Item{c, (links[(size_t)c].hit & LEAF_FLAG) ? i : c, level});
+    }
   };
   auto area = [&](int i) {
     const TmpLink& l = links[(size_t)i];

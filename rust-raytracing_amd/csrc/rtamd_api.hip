@@ -532,12 +532,13 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   // Scenes of spheres only: the caller's tree in its four-wide form as well (see wide_from_links), which the double-precision
   // image takes when it does not fit in LDS.  RTAMD_NO_WIDE=1 / RTAMD_F64_LIST=1 keep the list.
   std::vector<WideTmp> wide64;
+  std::vector<uint32_t> pre64;  // leaves kept outside that tree, tested ahead of the walk
   const bool want_wide64 = preset == PRESET_BALLS_LDS && !std::getenv("RTAMD_NO_WIDE") && !std::getenv("RTAMD_F64_LIST");
   auto fold64 = [&](const std::vector<TmpLink>& list, int list_root) {
     if (!want_wide64) return;
     const FastTreeBuilder shapes_of(*s);  // sphere scenes have no nested trees: the caller's objects as they are
-    const int need = wide_from_links(list, list_root, wide64, &shapes_of);
-    if (need > (int)kWideStack) wide64.clear();
+    const int need = wide_from_links(list, list_root, wide64, &shapes_of, &pre64);
+    if (need > (int)kWideStack) { wide64.clear(); pre64.clear(); }
     if (timing) std::fprintf(stderr, "rt_upload_scene: caller's tree four-wide: %zu nodes, stack need %d (limit %u)\n", wide64.size(), need, kWideStack);
   };
   if (!relinked) fold64(lb.links, root);
@@ -597,8 +598,8 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   const int device = c->device;
   std::thread t_sd([&] {
     if (hipSetDevice(device) != hipSuccess) { rc_sd = RT_E_HIP; err_sd = "hipSetDevice failed"; return; }
-    rc_sd = relinked ? build_image<double>(c, scene64, links64, root64, sub_root64, preset64, c->sd, &wide64, nullptr)
-                        : build_image<double>(c, *s, links, root, sub_root, preset, c->sd, &wide64, nullptr);
+    rc_sd = relinked ? build_image<double>(c, scene64, links64, root64, sub_root64, preset64, c->sd, &wide64, &pre64)
+                        : build_image<double>(c, *s, links, root, sub_root, preset, c->sd, &wide64, &pre64);
     if (rc_sd != RT_OK) err_sd = g_err;
   });
   // RT_F64_OWN_TREE: the library's tree once more, in double
