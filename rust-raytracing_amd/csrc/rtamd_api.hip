@@ -541,7 +541,11 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     if (need > (int)kWideStack) { wide64.clear(); pre64.clear(); }
     if (timing) std::fprintf(stderr, "rt_upload_scene: caller's tree four-wide: %zu nodes, stack need %d (limit %u)\n", wide64.size(), need, kWideStack);
   };
-  if (!relinked) fold64(lb.links, root);
+  // the folding reads its list only and runs on a thread of its own while this one goes on to the library's own tree
+  std::vector<TmpLink> fold_list;
+  std::thread t_fold;
+  struct JoinOnExit { std::thread& t; ~JoinOnExit() { if (t.joinable()) t.join(); } } fold_guard{t_fold};
+  if (!relinked && want_wide64) t_fold = std::thread([&, root] { fold64(lb.links, root); });
   if (relinked) {
     LinkBuilder lbs(scene64);
     lbs.splice = &splice;
@@ -551,8 +555,12 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     for (int i = 0; i < s->n_objects && lbs.err.empty(); ++i)
       if ((s->objects[i].flags & RT_OBJ_SUB_BVH) && !splice[(size_t)i]) sub_root64[(size_t)i] = lbs.node(s->objects[i].geom, LINK_END, 0, tree64++);
     if (!lbs.err.empty()) return fail(RT_E_INVALID, "rt_upload_scene: " + lbs.err);
-    fold64(lbs.links, root64);
+    const int root_before = root64;
     links64 = reorder(lbs.links, root64, sub_root64);
+    if (want_wide64) {
+      fold_list.swap(lbs.links);
+      t_fold = std::thread([&, root_before] { fold64(fold_list, root_before); });
+    }
     if (has_nested && !nested_left64 && preset == PRESET_ALL_LDS) preset64 = PRESET_FLATALL_LDS;
     mark("f64 list: nested trees spliced, copies left out");
   }
@@ -596,6 +604,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   int rc_sd = RT_OK, rc_own = RT_OK;
   std::string err_sd, err_own;
   const int device = c->device;
+  if (t_fold.joinable()) t_fold.join();
   std::thread t_sd([&] {
     if (hipSetDevice(device) != hipSuccess) { rc_sd = RT_E_HIP; err_sd = "hipSetDevice failed"; return; }
     rc_sd = relinked ? build_image<double>(c, scene64, links64, root64, sub_root64, preset64, c->sd, &wide64, &pre64)
