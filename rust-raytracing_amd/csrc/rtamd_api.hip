@@ -536,6 +536,30 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   const bool want_wide64 = preset == PRESET_BALLS_LDS && !std::getenv("RTAMD_NO_WIDE") && !std::getenv("RTAMD_F64_LIST");
   auto fold64 = [&](const std::vector<TmpLink>& list, int list_root) {
     if (!want_wide64) return;
+    // Two objects with the same geometry that are not copies of one another (different materials) would tie on every ray that hits
+    // them, and then the order of the tests does decide: such a scene keeps the list.  (64-bit hashes of tag and parameters; a chance
+    // collision only costs the faster walk.)
+    {
+      std::vector<uint64_t> keys;
+      keys.reserve(list.size() / 2 + 1);
+      for (const TmpLink& l : list) {
+        if (!(l.hit & LEAF_FLAG)) continue;
+        const rt_shape& sh = s->shapes[s->objects[l.hit & LEAF_INDEX_MASK].geom];
+        uint64_t h = 0xCBF29CE484222325ull ^ (uint64_t)(uint32_t)sh.tag;
+        for (int k = 0; k < 9; ++k) {
+          uint64_t b;
+          std::memcpy(&b, &sh.p[k], 8);
+          h = (h ^ b) * 0x100000001B3ull;
+          h ^= h >> 29;
+        }
+        keys.push_back(h);
+      }
+      std::sort(keys.begin(), keys.end());
+      if (std::adjacent_find(keys.begin(), keys.end()) != keys.end()) {
+        if (timing) std::fprintf(stderr, "rt_upload_scene: caller's tree keeps the list walk (coincident objects)\n");
+        return;
+      }
+    }
     const FastTreeBuilder shapes_of(*s);  // sphere scenes have no nested trees: the caller's objects as they are
     const int need = wide_from_links(list, list_root, wide64, &shapes_of, &pre64);
     if (need > (int)kWideStack) { wide64.clear(); pre64.clear(); }

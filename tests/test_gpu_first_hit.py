@@ -335,6 +335,23 @@ def test_f64_wide_walk_of_the_callers_tree_is_exact(gpu, rtamd, oracle, earth_rg
     assert (np.abs(fa - fb) / (np.abs(fb) + 1e-3)).max() < 1e-12
 
 
+def test_coincident_spheres_keep_the_list_walk(gpu, rtamd, oracle, earth_rgb):
+    """Two spheres with the same centre and radius but different materials tie on every ray that hits them, and which one the
+    reference reports hangs on the order of its walk: a sphere scene that holds such a pair must keep the list walk of the caller's
+    tree in double precision (preset 5 / 6 instead of the four-wide 9)."""
+    from custom_scene import EditedScene
+    hs, _ = make_pair(rtamd, oracle, "random", earth=earth_rgb)
+    gpu.upload(hs)
+    assert gpu.render_accum(None, 0, 1, precision=rtamd.F64, seed=3)["scene_in_lds"] == 9
+    ed = EditedScene(rtamd, hs)
+    spheres = np.nonzero(ed.shapes["tag"] == 0)[0]
+    a, b = next((int(x), int(y)) for x in spheres for y in spheres if x < y and ed.shapes["material"][x] != ed.shapes["material"][y])
+    ed.shapes["p"][b] = ed.shapes["p"][a]
+    gpu.upload(ed)
+    assert gpu.render_accum(None, 0, 1, precision=rtamd.F64, seed=3)["scene_in_lds"] in (5, 6)
+    gpu.upload(hs)
+
+
 @pytest.mark.parametrize("name,mega_grid", [("random", 0), ("final-scene", 0), ("mega-spheres", 40), ("cornell-box", 0)])
 def test_f64_on_the_librarys_own_tree(gpu, rtamd, oracle, earth_rgb, name, mega_grid):
     """RT_F64_OWN_TREE: double arithmetic on the tree the library builds for itself.  Checked against the ORACLE like the default
