@@ -453,6 +453,9 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? (sizeof(R) == 8 ? RT_NESTED
 #ifndef RT_STEP_WAVES_FULL_F64
 #define RT_STEP_WAVES_FULL_F64 3  // double precision: final-scene on the library's tree 3.71 / 3.95 / 3.83 Grays/s at 4 / 3 / 2 waves per SIMD, on the caller's tree no difference
 #endif
+#ifndef RT_WIDE_WAVES_F32
+#define RT_WIDE_WAVES_F32 0  // != 0: waves per SIMD asked for the single-precision four-wide kernels (measurement switch; needs RT_WIDE_STACK to match the LDS)
+#endif
 #ifndef RT_STEP_THREADS
 #define RT_STEP_THREADS 256
 #endif
@@ -480,7 +483,7 @@ constexpr int kTurnsPerCheck = RT_TURNS;
 constexpr int kWideStepsPerTurn = RT_WIDE_STEPS;  // node steps of the four-wide walk between two looks at the waiting leaves
 
 template <class R, class C, bool FIXED_GRAB, bool DEFER_LIST = false>
-__global__ __launch_bounds__(RT_STEP_THREADS, C::has(F_NESTED) ? RT_NESTED_WAVES : (C::has(F_NOISE) ? (sizeof(R) == 8 ? RT_STEP_WAVES_FULL_F64 : RT_STEP_WAVES_FULL) : RT_STEP_WAVES)) void k_paths_stepwise(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
+__global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == WALK_LANE_WIDE && sizeof(R) == 4) ? RT_WIDE_WAVES_F32 : C::has(F_NESTED) ? RT_NESTED_WAVES : (C::has(F_NOISE) ? (sizeof(R) == 8 ? RT_STEP_WAVES_FULL_F64 : RT_STEP_WAVES_FULL) : RT_STEP_WAVES)) void k_paths_stepwise(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
                                                         unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
   extern __shared__ __align__(16) uint8_t lds[];
   const SceneView<R, C> sv = make_view<R, C>(sc, lds);
