@@ -60,6 +60,9 @@ RT_DEV bool rect_t(R a0, R a1, R b0, R b1, R k, const Ray<R>& ray, const RI& ri,
   return ok;
 }
 
+template <class R> struct RayRcp;
+template <class R> RT_DEV bool box_slab_t(const DShape<R>& s, const Ray<R>& ray, const RayRcp<R>& ri, R t_min, R t_max, int self_side, R& t_out, int& side_out);
+
 // hit() of one shape reduced to its t (and the side of a box).  `self_side` as in shape_hit.
 template <class R, class C>
 RT_DEV bool shape_t(const DShape<R>& s, const Ray<R>& ray, const RayInv<R>& ri, R t_min, R t_max, int self_side, R& t_out, int& side_out) {
@@ -77,7 +80,12 @@ RT_DEV bool shape_t(const DShape<R>& s, const Ray<R>& ray, const RayInv<R>& ri, 
     case SH_RECT_XY: if constexpr (C::has(F_RECT)) { if (!self && rect_t<R, 2>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], ray, ri, t_min, t_max, t_out)) { side_out = -1; hit = true; } } break;
     case SH_RECT_XZ: if constexpr (C::has(F_RECT)) { if (!self && rect_t<R, 1>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], ray, ri, t_min, t_max, t_out)) { side_out = -1; hit = true; } } break;
     case SH_RECT_YZ: if constexpr (C::has(F_RECT)) { if (!self && rect_t<R, 0>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], ray, ri, t_min, t_max, t_out)) { side_out = -1; hit = true; } } break;
-    case SH_BOX: if constexpr (C::has(F_BOX)) {  // six sides in the order of src/box_struct.rs:22-71; a later side wins a tie
+    case SH_BOX: if constexpr (C::has(F_BOX) && (sizeof(R) == sizeof(float) || C::walk == WALK_LANE_WIDE)) {
+      // single precision, and double precision on the library's own tree (compared with the reference by tolerance): the six sides as
+      // three slabs, with the reference's side numbering and tie order - a third of the instructions of six rectangle tests, and in
+      // double precision no division
+      hit = box_slab_t<R>(s, ray, RayRcp<R>(ri.inv, 0), t_min, t_max, self ? self_side : -2, t_out, side_out);
+    } else if constexpr (C::has(F_BOX)) {  // six sides in the order of src/box_struct.rs:22-71; a later side wins a tie
       R lox = s.p[0], loy = s.p[1], loz = s.p[2], hix = s.p[3], hiy = s.p[4], hiz = s.p[5];
       R closest = t_max;
       if (!(self && self_side == 0) && rect_t<R, 2>(lox, hix, loy, hiy, hiz, ray, ri, t_min, closest, closest)) { side_out = 0; hit = true; }
@@ -286,6 +294,7 @@ RT_DEV double next_up(double x) { return nextafter(x, Lim<double>::inf()); }
 template <class R> struct RayRcp {
   V3<R> inv;
   RT_DEV explicit RayRcp(V3<R> dir) : inv(flat_rcp(dir.x), flat_rcp(dir.y), flat_rcp(dir.z)) {}
+  RT_DEV RayRcp(V3<R> reciprocals, int) : inv(reciprocals) {}  // from reciprocals the caller already has
   template <int AXIS> RT_DEV R quot(R num) const { return num * (AXIS == 0 ? inv.x : AXIS == 1 ? inv.y : inv.z); }
 };
 
