@@ -143,6 +143,37 @@ RT_DEV bool sphere_roots(V3<float> center, const Ray<float>& ray, float radius, 
   return near_ok | far_ok;
 }
 
+// Both roots of the same quadratic, formed exactly as sphere_roots forms them (no range applied); false when the line misses the
+// sphere.  What a ConstantMedium asks of a spherical boundary - the first crossing of the whole line, then the first one at least
+// 0.0001 later (src/constant_medium.rs:50-60) - is the smaller root and then the larger one: one evaluation instead of two.
+RT_DEV bool sphere_span(V3<double> center, const Ray<double>& ray, double radius, double& near, double& far) {
+#pragma clang fp contract(off)
+  V3<double> oc = ray.o - center;
+  double a = length_squared(ray.d);
+  double half_b = dot(oc, ray.d);
+  double c = length_squared(oc) - radius * radius;
+  double discriminant = half_b * half_b - a * c;
+  if (discriminant < 0.0) return false;
+  double sqrt_d = rt_sqrt(discriminant);
+  near = (-half_b - sqrt_d) / a;
+  far = (-half_b + sqrt_d) / a;
+  return true;
+}
+RT_DEV bool sphere_span(V3<float> center, const Ray<float>& ray, float radius, float& near, float& far) {
+  double ocx = (double)ray.o.x - (double)center.x, ocy = (double)ray.o.y - (double)center.y, ocz = (double)ray.o.z - (double)center.z;
+  double dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+  double a = dx * dx + dy * dy + dz * dz;
+  double half_b = ocx * dx + ocy * dy + ocz * dz;
+  double c = ocx * ocx + ocy * ocy + ocz * ocz - (double)radius * (double)radius;
+  double discriminant = half_b * half_b - a * c;
+  if (discriminant < 0.0) return false;
+  const float inv_a = __builtin_amdgcn_rcpf((float)a);
+  const double sqrt_d = radius * radius > 1.0e4f ? __builtin_sqrt(discriminant) : (double)__builtin_amdgcn_sqrtf((float)discriminant);
+  near = (float)(-half_b - sqrt_d) * inv_a;
+  far = (float)(-half_b + sqrt_d) * inv_a;
+  return true;
+}
+
 // One axis-aligned rectangle.  AXIS is the constant axis; (A, B) the in-plane axes in the reference's (u, v) order.
 template <class R, int AXIS, bool UV>
 RT_DEV bool rect_hit(R a0, R a1, R b0, R b1, R k, int material, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec) {  // src/aarect.rs:88-107

@@ -147,12 +147,27 @@ RT_DEV bool leaf_t(const SceneView<R, C>& sv, uint32_t leaf_word, const Ray<R>& 
           const R inf = Lim<R>::inf();
           R t1, t2;
           int unused;
-          if (!boundary_t<R, C>(ob, s, ray, ri, -inf, inf, -2, t1, unused)) return false;
+          const bool ball = s.tag == SH_SPHERE || s.tag == SH_MOVING;
+          if (ball) {  // both crossings from one evaluation of the quadratic (see sphere_span)
+            if constexpr (C::has(F_SPHERE) || C::has(F_MOVING)) {
+              Ray<R> moved = ray, local = ray;
+              if constexpr (C::has(F_XFORM)) {
+                if (ob.flags & (OBJ_TRANSLATE | OBJ_ROTATE_Y)) to_local(ob, ray, moved, local);
+              }
+              const V3<R> center = s.tag == SH_SPHERE ? V3<R>(s.p[0], s.p[1], s.p[2]) : moving_center(s, local.time);
+              if (!sphere_span(center, local, s.tag == SH_SPHERE ? s.p[3] : s.p[6], t1, t2)) return false;
+            } else {
+              return false;
+            }
+          } else if (!boundary_t<R, C>(ob, s, ray, ri, -inf, inf, -2, t1, unused)) {
+            return false;
+          }
           R t_after = t1 + (R)0.0001;
           if constexpr (Guard<R>::on) {
             if (!(t_after > t1)) t_after = nextafterf(t1, Lim<float>::inf());  // see object_hit
           }
-          if (!boundary_t<R, C>(ob, s, ray, ri, t_after, inf, -2, t2, unused)) return false;
+          if (ball) { if (t2 < t_after) return false; }
+          else if (!boundary_t<R, C>(ob, s, ray, ri, t_after, inf, -2, t2, unused)) return false;
           if (t1 < t_min) t1 = t_min;
           if (t2 > t_max) t2 = t_max;
           if (t1 >= t2) return false;
