@@ -75,7 +75,7 @@ template <class R> RT_DEV V3<R> operator-(V3<R> v) { return V3<R>(-v.x, -v.y, -v
 template <class R> RT_DEV R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          // src/vec3.rs:58-60
 template <class R> RT_DEV R length_squared(V3<R> v) { return v.x * v.x + v.y * v.y + v.z * v.z; }         // src/vec3.rs:49-51
 template <class R> RT_DEV R length(V3<R> v) { return rt_sqrt(length_squared(v)); }                        // src/vec3.rs:45-47
-RT_DEV V3<double> vdiv(V3<double> v, double f) { return (1.0 / f) * v; }                                  // src/vec3.rs:224-230
+RT_DEV V3<double> vdiv(V3<double> v, double f) { return rcp_refined(f) * v; }  // (1.0 / f) * v of src/vec3.rs:224-230; the refined reciprocal is that quotient bit for bit
 RT_DEV V3<float> vdiv(V3<float> v, float f) { return __builtin_amdgcn_rcpf(f) * v; }                      // hardware reciprocal (1 ulp)
 RT_DEV V3<double> unit_vector(V3<double> v) { return vdiv(v, length(v)); }                                // src/vec3.rs:77-79
 RT_DEV V3<float> unit_vector(V3<float> v) { return __builtin_amdgcn_rsqf(length_squared(v)) * v; }        // hardware 1/sqrt (1 ulp)
