@@ -475,6 +475,10 @@ constexpr uint32_t kLeafLanes = RT_LEAF_LANES;
 #endif
 constexpr uint32_t kLeafLanesCostly = RT_LEAF_LANES_COSTLY;
 constexpr uint32_t kRestartLanes = RT_RESTART_LANES;
+#ifndef RT_RESTART_LANES_WIDE
+#define RT_RESTART_LANES_WIDE 40  // the four-wide walk: 32 / 40 / 48 idle lanes measure 9.5 / 9.8 / 9.8 Grays/s on the million-sphere field, 8.55 / 8.63 / 8.42 on final-scene
+#endif
+constexpr uint32_t kRestartLanesWide = RT_RESTART_LANES_WIDE;
 constexpr int kBoxStepsPerTurn = RT_BOX_STEPS;
 constexpr int kTurnsPerCheck = RT_TURNS;
 #ifndef RT_WIDE_STEPS
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
                     // [5] leaf steps, [7] restarts, and the number of [4] box steps, [6] leaf steps (restarts: [7] / lanes per restart)
   for (;;) {
     const unsigned long long idle = __ballot(i < 0);
-    if ((uint32_t)__popcll(idle) >= kRestartLanes || idle == ~0ull) {
+    if ((uint32_t)__popcll(idle) >= (WIDE ? kRestartLanesWide : kRestartLanes) || idle == ~0ull) {
       bool to_scatter = false;
       if constexpr (DEFER) {
         if (i < 0 && active && best_leaf >= 0) {  // the walk has ended on a hit: its record, once
