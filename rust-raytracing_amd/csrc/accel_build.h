@@ -188,10 +188,27 @@ class FastTreeBuilder {
     struct Slot { uint64_t hash; int obj; };
     std::vector<Slot> table(cap, Slot{0, -1});
     std::vector<int> slot_of((size_t)s_.n_objects, -1);
-    for (int o : order) {
+    // the hashes of all signatures first, on threads (most of the time of this search for a million objects); the table is then
+    // filled in walk order by one thread
+    std::vector<uint64_t> hash_of(order.size());
+    {
+      unsigned hw = std::thread::hardware_concurrency();
+      if (const char* e = std::getenv("OMP_NUM_THREADS")) hw = std::min<unsigned>(hw ? hw : 1u, (unsigned)std::max(1, atoi(e)));
+      const size_t n_threads = order.size() < 65536 ? 1 : std::max(1u, std::min(hw, 16u));
+      std::vector<std::thread> pool;
+      auto work = [&](size_t lo, size_t hi) {
+        for (size_t q = lo; q < hi; ++q) hash_of[q] = eligible(order[q]) ? (uint64_t)SignatureHash()(signature(order[q])) : 0ull;
+      };
+      const size_t per = (order.size() + n_threads - 1) / n_threads;
+      for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work, std::min(order.size(), t * per), std::min(order.size(), (t + 1) * per));
+      work(0, std::min(order.size(), per));
+      for (std::thread& t : pool) t.join();
+    }
+    for (size_t q = 0; q < order.size(); ++q) {
+      const int o = order[q];
       if (!eligible(o)) continue;
       const Signature g = signature(o);
-      const uint64_t h = (uint64_t)SignatureHash()(g);
+      const uint64_t h = hash_of[q];
       size_t k = (size_t)h & (cap - 1);
       while (table[k].obj >= 0 && !(table[k].hash == h && signature(table[k].obj) == g)) k = (k + 1) & (cap - 1);
       table[k] = Slot{h, o};  // a later copy takes the place of an earlier one
