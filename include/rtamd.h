@@ -188,7 +188,13 @@ typedef struct rt_stats {
   uint64_t passes;
   uint32_t lds_bytes;          /* LDS used per workgroup by the bounce kernel */
   uint32_t scene_in_lds;       /* kernel preset the scene selected: 0 boxes, 1 smoke, 2 spheres, 3 all (scene in LDS), 4 all (top links in LDS), 5/6 spheres-only lane walk (LDS / top links), 7/8 all without nested trees (images whose nested trees were dissolved or spliced), 9/10 spheres-only / all without nested trees on the four-wide form of the library's own tree */
+  uint32_t kernel_variant;     /* PERSISTENT pipeline: which instantiation of the path kernel ran, RT_VARIANT_* bits */
+  uint32_t pad;
 } rt_stats;
+#define RT_VARIANT_FIXED_GRAB 1u       /* paths handed out in constant grabs of 2048 per wave (large frames) */
+#define RT_VARIANT_CHUNKED 2u          /* a lane sums up to 16 samples of one pixel before its one atomic add (cheap bright paths) */
+#define RT_VARIANT_STEPWISE 4u         /* k_paths_stepwise (per-lane tree walks) instead of k_paths_persistent */
+#define RT_VARIANT_DEFERRED_RECORDS 8u /* double precision on the caller's tree: hit record built once, after the walk */
 
 typedef struct rt_context rt_context;
 
@@ -250,13 +256,15 @@ int rt_comm_destroy(rt_context* ctx);
  * are left unchanged. */
 int rt_reduce_accum(rt_context* ctx, void* accum_dev, uint32_t width, uint32_t height, int precision, int root);
 
-/* rt_render() for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid
- * hipMalloc.  No counterpart in the reference (its render() allocates freely); it exists for those callers only.
+/* rt_render() for callers that cannot allocate: tight serving loops, harnesses that forbid hipMalloc, hosts that must not
+ * fragment device memory.  No counterpart in the reference (its render() allocates freely); it exists for those callers only.
  * The call allocates and frees nothing, on the device or through any allocating routine: the counters and the RGB8 staging
  * image live in a static device array inside the library (about 24 MiB on every GPU the library runs on, held until the process
- * ends), everything else is the caller's.
+ * ends), everything else is the caller's.  Allocation-free is all it promises: the call still synchronises the context's stream,
+ * reads two events and copies the ray count and the image to the host, none of which may run inside a HIP graph capture.
  *   accum_dev  DEVICE buffer of width*height*4 floats (F32) or doubles (F64), required; zeroed by the call, receives the sums
- *   rgb8_out   host buffer of width*height*3 bytes, required (page-locked memory makes the copy one DMA)
+ *   rgb8_out   host buffer of width*height*3 bytes, required (page-locked memory makes the copy one DMA; a pageable buffer goes
+ *              through the runtime's own staging)
  * Limits: width*height <= 3840*2160 (RT_E_INVALID beyond), pipeline AUTO or PERSISTENT (RT_E_UNSUPPORTED otherwise).
  * Every call on a GPU uses that GPU's one scratch array: calls that overlap on the same GPU (two contexts, two threads) race. */
 int rt_render_noalloc(rt_context* ctx, const rt_render_params* params, void* accum_dev, uint8_t* rgb8_out, rt_stats* stats);

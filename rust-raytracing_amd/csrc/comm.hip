@@ -32,11 +32,32 @@ int load_rccl(const Rccl** out) {
   std::lock_guard<std::mutex> lock(g_rccl_mutex);
   if (!g_rccl.lib) {
     void* h = nullptr;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (h) break;
+    std::string why;
+    // RTAMD_RCCL_LIB names the library to open instead of the usual ones (a host with RCCL somewhere else; tests of the
+    // "RCCL is not installed" path).
+    const char* forced = getenv("RTAMD_RCCL_LIB");
+    const char* usual[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // A process that already maps an RCCL (torch.distributed's, say) gets that one: RTLD_NOLOAD finds a library that is loaded
+    // and loads nothing, so the process never ends up with two RCCL instances side by side.
+    if (!forced)
+      for (const char* name : usual) {
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+        if (h) break;
+      }
+    if (!h) {
+      if (forced) {
+        h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!h) { const char* e = dlerror(); why = e ? e : "not found"; }
+      } else {
+        for (const char* name : usual) {
+          h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+          if (h) break;
+          const char* e = dlerror();  // one call: it hands the message over and clears it
+          if (why.empty()) why = e ? e : "librccl.so.1 not found";
+        }
+      }
     }
-    if (!h) return fail(RT_E_UNSUPPORTED, std::string("RCCL is not available: ") + (dlerror() ? dlerror() : "librccl.so.1 not found"));
+    if (!h) return fail(RT_E_UNSUPPORTED, "RCCL is not available: " + (why.empty() ? std::string("librccl.so.1 not found") : why));
     Rccl r;
     r.lib = h;
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));

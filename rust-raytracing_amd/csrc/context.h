@@ -102,6 +102,8 @@ struct rt_context {
   unsigned long long* d_ray_count = nullptr;
   void* accum = nullptr;
   size_t accum_bytes = 0;
+  uint8_t* d_rgb = nullptr;  // rt_resolve: the RGB8 image on the device, before its copy to the host
+  size_t rgb_bytes = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   unsigned long long* h_rays = nullptr;  // one page-locked host word: where the allocation-free entry point receives its ray count
   // progressive rendering (rt_progress_*): the frame in progress and the next sample to render

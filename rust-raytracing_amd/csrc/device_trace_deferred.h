@@ -153,7 +153,7 @@ RT_DEV bool leaf_t(const SceneView<R, C>& sv, uint32_t leaf_word, const Ray<R>& 
       if constexpr (C::has(F_MEDIUM)) {
         if (ob.flags & OBJ_MEDIUM) {  // src/constant_medium.rs:41-111
           const R inf = Lim<R>::inf();
-          R t1, t2;
+          R t1 = (R)0, t2 = (R)0;
           int unused;
           const bool ball = s.tag == SH_SPHERE || s.tag == SH_MOVING;
           if (ball) {  // both crossings from one evaluation of the quadratic (see sphere_span)

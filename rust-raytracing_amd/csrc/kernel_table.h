@@ -2,6 +2,7 @@
 // own (kt_*.hip) so the presets compile in parallel and the f64 ones can be built without multiply-add contraction.
 #pragma once
 #include "kernels.h"
+#include "rtamd.h"
 
 namespace rti {
 using namespace rtd;
@@ -10,8 +11,9 @@ template <class R> struct KernelTable {
   uint32_t (*lds_bytes)(const BlobLayout& lay, uint32_t lds_links);
   void (*bounce_fused)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, PathQueue<R> in, PathQueue<R> out,
                        uint32_t* counters, uint32_t* cursors, unsigned long long* ray_count, R* accum, uint32_t bounce);
-  void (*paths_persistent)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, unsigned long long total_paths,
-                           unsigned long long* path_cursor, unsigned long long* ray_count, R* accum);
+  // returns which instantiation it launched: RT_VARIANT_* bits (rtamd.h: rt_stats.kernel_variant)
+  uint32_t (*paths_persistent)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, unsigned long long total_paths,
+                               unsigned long long* path_cursor, unsigned long long* ray_count, R* accum);
   int (*resident_blocks_per_cu)(int kernel, uint32_t lds);  // kernel: 0 bounce_fused, 1 trace, 2 shade, 3 paths_persistent
   void (*trace)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, PathQueue<R> in, HitQueue<R> hits,
                 uint32_t* counters, uint32_t* cursors, unsigned long long* ray_count, uint32_t* class_counters, uint32_t* class_index, uint32_t capacity, R* accum,
@@ -49,29 +51,32 @@ template <class R, class C> KernelTable<R> make_table() {
     hipLaunchKernelGGL((k_bounce_fused<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, in, out, counters, cursors, ray_count, accum, bounce);
   };
   t.paths_persistent = [](uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, unsigned long long total_paths,
-                          unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
+                          unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) -> uint32_t {
     const bool fixed = fp.path_grab == kPathGrab;
+    const uint32_t vf = fixed ? RT_VARIANT_FIXED_GRAB : 0u;
     if constexpr (!use_stepwise<C>()) {
       if constexpr (chunked_variant<C>()) {
         if (fp.chunk > 1u) {
           if (fixed) hipLaunchKernelGGL((k_paths_persistent<R, C, true, true>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
           else hipLaunchKernelGGL((k_paths_persistent<R, C, false, true>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
-          return;
+          return vf | RT_VARIANT_CHUNKED;
         }
       }
       if (fixed) hipLaunchKernelGGL((k_paths_persistent<R, C, true>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
       else hipLaunchKernelGGL((k_paths_persistent<R, C, false>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
+      return vf;
     }
     else {
       if constexpr (list_defer_variant<R, C>()) {
         if (sc.defer_ok) {
           if (fixed) hipLaunchKernelGGL((k_paths_stepwise<R, C, true, true>), dim3(grid), dim3(kStepThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
           else hipLaunchKernelGGL((k_paths_stepwise<R, C, false, true>), dim3(grid), dim3(kStepThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
-          return;
+          return vf | RT_VARIANT_STEPWISE | RT_VARIANT_DEFERRED_RECORDS;
         }
       }
       if (fixed) hipLaunchKernelGGL((k_paths_stepwise<R, C, true>), dim3(grid), dim3(kStepThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
       else hipLaunchKernelGGL((k_paths_stepwise<R, C, false>), dim3(grid), dim3(kStepThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
+      return vf | RT_VARIANT_STEPWISE;
     }
   };
   t.resident_blocks_per_cu = [](int kernel, uint32_t lds) {

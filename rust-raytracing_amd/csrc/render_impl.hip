@@ -352,10 +352,14 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
       const char* e = getenv("RTAMD_GRABS_PER_WAVE");
       const uint64_t per = total_paths / (waves * (e ? (uint64_t)std::max(1, atoi(e)) : 16u));
       fp.path_grab = (uint32_t)std::min<uint64_t>(kPathGrab, std::max<uint64_t>(e ? 64u : 256u, per / 64u * 64u));
+      // RTAMD_FIXED_GRAB=1: the grab of large frames (and with it the kernel instantiations that fold it as a constant) whatever
+      // the frame size, so that those instantiations can be run on frames small enough to compare with a CPU evaluation
+      if (getenv("RTAMD_FIXED_GRAB")) fp.path_grab = kPathGrab;
     }
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    uint32_t variant = 0;
     if (p.max_depth > 0 && total_paths > 0)
-      im.table.paths_persistent(grid, im.lds_bytes, c->stream, im.dev, fp, total_paths, cnt + 8, cnt, accum);
+      variant = im.table.paths_persistent(grid, im.lds_bytes, c->stream, im.dev, fp, total_paths, cnt + 8, cnt, accum);
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     HIP_TRY(hipGetLastError());
     unsigned long long rays_stack = 0;
@@ -394,6 +398,7 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
       stats->passes = 1;
       stats->lds_bytes = im.lds_bytes;
       stats->scene_in_lds = (uint32_t)im.preset;
+      stats->kernel_variant = variant;
     }
     return RT_OK;
   }

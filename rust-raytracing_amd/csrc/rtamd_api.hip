@@ -286,6 +286,7 @@ void rt_destroy(rt_context* c) {
   free_scene(c);
   if (c->ws) (void)hipFree(c->ws);
   if (c->accum) (void)hipFree(c->accum);
+  if (c->d_rgb) (void)hipFree(c->d_rgb);
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->d_ray_count) (void)hipFree(c->d_ray_count);
   if (c->h_rays) (void)hipHostFree(c->h_rays);
@@ -303,6 +304,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
   free_scene(c);
+  c->progress_active = false;  // a frame in progress belonged to the scene that is being replaced
 
   // RTAMD_TIMING=1: seconds spent in each stage of the upload, on stderr
   const bool timing = std::getenv("RTAMD_TIMING") != nullptr;
@@ -661,6 +663,9 @@ int rt_render_accum(rt_context* c, const rt_render_params* p, void* accum_dev, r
   if (accum_dev)
     if (int bad = check_device_buffer(accum_dev, "rt_render_accum")) return bad;
   if (stats) std::memset(stats, 0, sizeof(*stats));
+  // NULL = the context's own buffer, cleared (and possibly reallocated) by this call: a progressive frame that was being
+  // refined in it is over, and its next rt_progress_step says so instead of resolving a picture of the wrong sums
+  if (!accum_dev) c->progress_active = false;
   rt_render_params q = *p;
   q.precision = select_tree(c, p->precision);
   if (q.precision == RT_PRECISION_F64) return render_accum_impl<double>(c, q, accum_dev, stats);
@@ -679,14 +684,19 @@ int rt_resolve(rt_context* c, const void* accum_dev, uint32_t width, uint32_t he
     if (!c->accum || c->accum_bytes < need) return fail(RT_E_INVALID, "the context holds no accumulation buffer of this size");
     accum_dev = c->accum;
   }
-  uint8_t* d_rgb = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_rgb, n * 3));
+  // the RGB8 image between the conversion kernel and the copy to the host: kept by the context and grown on demand, so that a
+  // render loop (one rt_resolve per frame) allocates nothing after its first frame
+  if (c->rgb_bytes < n * 3) {
+    if (c->d_rgb) (void)hipFree(c->d_rgb);
+    c->d_rgb = nullptr; c->rgb_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&c->d_rgb, n * 3));
+    c->rgb_bytes = n * 3;
+  }
+  uint8_t* const d_rgb = c->d_rgb;
   int rrc = precision == RT_PRECISION_F64 ? resolve_impl<double>(c, accum_dev, n, spp, d_rgb) : resolve_impl<float>(c, accum_dev, n, spp, d_rgb);
-  if (rrc) { (void)hipFree(d_rgb); return rrc; }
-  hipError_t e = hipSuccess;
-  if (e == hipSuccess) e = hipMemcpyAsync(rgb8_out, d_rgb, n * 3, hipMemcpyDeviceToHost, c->stream);
+  if (rrc) return rrc;
+  hipError_t e = hipMemcpyAsync(rgb8_out, d_rgb, n * 3, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(d_rgb);
   if (e != hipSuccess) return fail(RT_E_HIP, std::string("rt_resolve: ") + hipGetErrorString(e));
   return RT_OK;
 }
@@ -743,7 +753,9 @@ int rt_progress_begin(rt_context* c, const rt_render_params* p) {
 
 int rt_progress_step(rt_context* c, uint32_t max_samples, uint8_t* rgb8_out, uint32_t* samples_done, int* finished, rt_stats* stats) {
   if (!c || !rgb8_out) return fail(RT_E_INVALID, "context or output is NULL");
-  if (!c->progress_active) return fail(RT_E_INVALID, "rt_progress_step before rt_progress_begin");
+  if (!c->progress_active)
+    return fail(RT_E_INVALID, "rt_progress_step without a frame in progress (no rt_progress_begin, or a scene upload / another render into the context's own "
+                              "buffer since then)");
   if (max_samples == 0) return fail(RT_E_INVALID, "max_samples is 0");
   if (!c->has_scene) return fail(RT_E_NO_SCENE, "no scene uploaded");
   const rt_render_params& f = c->progress;

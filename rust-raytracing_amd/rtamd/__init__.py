@@ -22,6 +22,7 @@ F64_OWN_TREE = F64 | 0x400  # double arithmetic on the tree the library builds f
 TRACE_AS_RENDERED = 0x100  # rt_trace_batch: records built by the render kernels' own configuration
 TRACE_VISITS = 0x200       # ... and u, v = box entries / leaves tested by the walk
 PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_SORTED, PIPELINE_PERSISTENT = 0, 1, 2, 3
+VARIANT_FIXED_GRAB, VARIANT_CHUNKED, VARIANT_STEPWISE, VARIANT_DEFERRED_RECORDS = 1, 2, 4, 8  # Stats.kernel_variant bits
 
 SCENES = {
     "random": 0, "two-spheres": 1, "two-perlin-spheres": 2, "earth": 3, "simple-light": 4,
@@ -51,7 +52,7 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("camera_rays", C.c_uint64), ("seconds", C.c_double), ("bounce_kernel_ms", C.c_double),
                 ("bounce_kernel_launches", C.c_uint64), ("gen_kernel_ms", C.c_double), ("passes", C.c_uint64),
-                ("lds_bytes", C.c_uint32), ("scene_in_lds", C.c_uint32)]
+                ("lds_bytes", C.c_uint32), ("scene_in_lds", C.c_uint32), ("kernel_variant", C.c_uint32), ("pad", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

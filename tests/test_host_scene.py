@@ -207,3 +207,40 @@ def test_scene_names(rtamd):
         assert H.rth_scene_from_name(name.encode()) == idx
         assert H.rth_scene_name(idx).decode() == name
     assert H.rth_scene_from_name(b"Cornell-Box") == -1
+
+
+def test_missing_rccl_is_reported_not_crashed(tmp_path):
+    """A host without RCCL: rt_comm_unique_id / rt_comm_init must return RT_E_UNSUPPORTED with a message, so that a caller can
+    fall back to its own exchange.  RTAMD_RCCL_LIB points the loader at a file that does not exist (and at one that is not a
+    library); a fresh process, because a library once loaded stays loaded."""
+    code = r"""
+import ctypes, os, sys
+lib = ctypes.CDLL(sys.argv[1])
+lib.rt_last_error.restype = ctypes.c_char_p
+buf = (ctypes.c_char * 128)()
+rc = lib.rt_comm_unique_id(ctypes.byref(buf))
+print(rc, lib.rt_last_error().decode())
+"""
+    junk = tmp_path / "librccl_not_a_library.so"
+    junk.write_text("this is not an ELF file\n")
+    for target in (str(tmp_path / "no_such_librccl.so"), str(junk)):
+        env = dict(os.environ, RTAMD_RCCL_LIB=target)
+        r = subprocess.run([os.sys.executable, "-c", code, os.path.join(BUILD, "librtamd.so")], capture_output=True, text=True, env=env, timeout=120)
+        assert r.returncode == 0, r.stderr
+        rc, msg = r.stdout.strip().split(" ", 1)
+        assert int(rc) == 5 and "RCCL is not available" in msg and len(msg) > 30, r.stdout
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    """include/rtamd.h and include/rtamd_host.h are C headers: a C11 translation unit that includes them and takes the address of
+    every declared function compiles with gcc (no C++ in between) and links against the two libraries."""
+    names = _declared_functions("rtamd.h") + _declared_functions("rtamd_host.h")
+    src = tmp_path / "abi.c"
+    src.write_text('#include "rtamd.h"\n#include "rtamd_host.h"\n#include <stdio.h>\n'
+                   "int main(void) {\n  const void* f[] = {%s};\n  printf(\"%%d %%s\\n\", (int)(sizeof f / sizeof f[0]), rt_version());\n"
+                   "  rt_context* c = 0; return rt_create(&c, 1 << 20) == RT_E_NO_DEVICE ? 0 : 1;\n}\n" % ", ".join("(const void*)%s" % n for n in names))
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-Wno-pedantic", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe),
+                           "-L", BUILD, "-lrtamd_host", "-lrtamd", "-Wl,-rpath," + BUILD, "-Wl,-rpath-link," + BUILD])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.split()[0] == str(len(names)) and "gfx950" in r.stdout, (r.returncode, r.stdout, r.stderr)

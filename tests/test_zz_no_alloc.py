@@ -3,7 +3,8 @@
 Two calls in a row on the same GPU, the second with a smaller frame and fewer samples: the static scratch (counters, RGB8
 staging) keeps the first call's contents, so the second call only comes out right if everything that must start at zero is
 cleared.  Bar: ray counts equal; sums within 1e-12 relative in f64 (the same paths; only the order of the atomic additions may
-differ) and 1e-4 in f32; RGB8 within 1 level, and equal in all but 1e-4 of the bytes.
+differ) and 1e-4 in f32; RGB8 within 1 level, and equal in all but 1e-4 of the bytes.  The free device memory that
+hipMemGetInfo reports must be the same after the call as before it.
 """
 import numpy as np
 import pytest
@@ -17,9 +18,13 @@ def _check(rtamd, gpu, torch, scene, spp, prec, seed):
     rgb_ref, acc_ref, st_ref = gpu.render(0, spp, precision=prec, seed=seed)
     dt = torch.float64 if prec == rtamd.F64 else torch.float32
     accum = torch.full((H * W * 4,), 7.0, dtype=dt, device="cuda:0")  # garbage on purpose: the call zeroes it
+    pinned = torch.full((H, W, 3), 99, dtype=torch.uint8).pin_memory()  # page-locked: the copy of the image is one DMA, no staging
+    rgb = pinned.numpy()
     torch.cuda.synchronize()
-    rgb = np.full((H, W, 3), 99, dtype=np.uint8)
+    free_before, _ = torch.cuda.mem_get_info(0)  # hipMemGetInfo: device memory free on this GPU
     st = gpu.render_noalloc(accum.data_ptr(), rgb, 0, spp, precision=prec, seed=seed)
+    free_after, _ = torch.cuda.mem_get_info(0)
+    assert free_after == free_before, "rt_render_noalloc changed the free device memory by %d bytes" % (free_before - free_after)
     got = accum.view(H, W, 4)[:, :, :3].double().cpu().numpy()
     assert st["rays"] == st_ref["rays"] and st["camera_rays"] == W * H * spp
     tol = 1e-12 if prec == rtamd.F64 else 1e-4
