@@ -93,8 +93,13 @@ def test_primary_rays_and_paths_at_bench_frame_sizes(gpu, rtamd, oracle, earth_r
     assert np.abs(grays["d"] - orays["d"]).max() < 1e-11
     assert np.abs(grays["time"] - orays["time"]).max() < 1e-15
     g32 = gpu.camera_rays(pixel, sample, seed=5, precision=rtamd.F32)
-    scale = np.abs(orays["d"]).max()
-    assert np.abs(g32["d"] - orays["d"]).max() < 2e-6 * scale and np.abs(g32["o"] - orays["o"]).max() < 1e-5
+    # single precision: a direction is a sum of camera vectors with coordinates of up to several hundred; half a dozen roundings of those
+    scale = max(1.0, np.abs(hs.camera()[:12]).max())
+    # (a camera with a lens: a disk candidate within rounding of the rim is accepted in one precision and not in the other, one ray
+    # in 10^5 or so; those rays are real rays of the same camera, just of another candidate)
+    d_err, o_err = np.abs(g32["d"] - orays["d"]).max(axis=1), np.abs(g32["o"] - orays["o"]).max(axis=1)
+    assert np.quantile(d_err, 0.9999) < 4e-7 * scale and np.quantile(o_err, 0.9999) < 1e-7 * scale, (d_err.max(), o_err.max())
+    assert (d_err > 4e-7 * scale).sum() <= (0 if hs.camera()[21] == 0.0 else 10)
     m = 20_000
     want = os_.sample_radiance(21, pixel[:m], sample[:m])
     got = gpu.sample_radiance(pixel[:m], sample[:m], seed=21, precision=rtamd.F64)
@@ -157,7 +162,11 @@ def test_million_spheres_at_3840x2160_against_the_oracle(gpu, rtamd, oracle):
         t_rel = np.abs(g32["t"][both] - oh["t"][both]) / np.abs(oh["t"][both])
         print("1M spheres, %s rays, f32: %.4f%% differ in ids; t rel err max %.3g, 99.9%% %.3g" % (label, 100 * (1 - same.mean()), t_rel.max(), np.quantile(t_rel, 0.999)))
         assert same.mean() > 0.999  # silhouettes of a million small spheres: a grazing ray may resolve either way in single precision
-        assert np.quantile(t_rel, 0.999) < 1e-5
+        if label == "camera":
+            assert np.quantile(t_rel, 0.999) < 1e-5
+        # origins anywhere make t itself ill-conditioned (a ray that starts next to a sphere): judged as a distance, like the other
+        # single-precision first-hit tests
+        assert dist_err(batch, g32, oh, both).max() < 1e-5
     # one whole frame of the configured size
     _, a64, s64 = gpu.render(0, 1, precision=rtamd.F64, seed=13)
     _, a32, s32 = gpu.render(0, 1, precision=rtamd.F32, seed=13)
