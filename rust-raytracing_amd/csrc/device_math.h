@@ -55,11 +55,26 @@ RT_DEV double rcp_refined(double x) {
   const double r2 = __builtin_fma(__builtin_fma(-x, r1, 1.0), r1, r1);
   return __builtin_amdgcn_div_fixup(r2, x, 1.0);
 }
+// The same with ONE Newton step: 0.6 ulp from the quotient on average, 11 at most (same probe), for the places that already multiply
+// by a reciprocal where the reference divides and so differ from it in the last digit either way (the flat walk's plane distances).
+RT_DEV double rcp_one_step(double x) {
+  const double r0 = __builtin_amdgcn_rcp(x);
+  const double r1 = __builtin_fma(__builtin_fma(-x, r0, 1.0), r0, r0);
+  return __builtin_amdgcn_div_fixup(r1, x, 1.0);
+}
 // 1/sqrt(x), hardware estimate and two Newton steps: within 2 ulp (same probe).
 RT_DEV double rsq_refined(double x) {
   const double s0 = __builtin_amdgcn_rsq(x);
   const double s1 = __builtin_fma(s0, __builtin_fma(-x * s0, 0.5 * s0, 0.5), s0);
   return __builtin_fma(s1, __builtin_fma(-x * s1, 0.5 * s1, 0.5), s1);
+}
+
+// One step: 1 ulp on average, 19 at most (same probe).  For the unit vector of a Lambertian bounce in the small-scene presets, whose direction
+// then differs from the reference's sqrt-then-divide by parts in 10^16 - the next hit point by as much, and nothing downstream
+// amplifies it there.
+RT_DEV double rsq_one_step(double x) {
+  const double s0 = __builtin_amdgcn_rsq(x);
+  return __builtin_fma(s0, __builtin_fma(-x * s0, 0.5 * s0, 0.5), s0);
 }
 
 template <class R> struct V3 {
@@ -100,14 +115,17 @@ template <class R> RT_DEV V3<R> refract(V3<R> uv, V3<R> n, R etai_over_etat) {  
 // src/constant_medium.rs:50, src/material.rs:127).
 // ---------------------------------------------------------------------------------------------
 constexpr int kPhiloxRounds = 7;
+// a ^ b ^ c in one instruction (gfx950's three-input bitwise operation with the truth table of a three-way exclusive or): a Philox
+// round ends in two of them, and written as two two-input operations each they are a sixth of a block's instructions
+RT_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 RT_DEV void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t& o0, uint32_t& o1,
                           uint32_t& o2, uint32_t& o3) {
 #pragma unroll
   for (int r = 0; r < kPhiloxRounds; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
+    uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
     c1 = (uint32_t)p1;
     c3 = (uint32_t)p0;
     c0 = n0;
@@ -246,7 +264,8 @@ RT_DEV void low3(uint32_t w0, uint32_t w1, uint32_t l[3]) {  // low words of the
   l[0] = m * 0x846CA68Bu; l[1] = (m + w1) * 0x9E3779B1u; l[2] = (m ^ w0) * 0x85EBCA77u;
 }
 RT_DEV void fields21(uint32_t w0, uint32_t w1, uint32_t& xi, uint32_t& yi, uint32_t& zi) {
-  xi = w0 >> 11; yi = ((w0 & 0x7FFu) << 10) | (w1 >> 22); zi = (w1 >> 1) & 0x1FFFFFu;
+  // bits 63..43, 42..22 and 21..1 of w0:w1: a shift, a funnel shift + mask, a bit-field extract
+  xi = w0 >> 11; yi = __builtin_amdgcn_alignbit(w0, w1, 22) & 0x1FFFFFu; zi = __builtin_amdgcn_ubfe(w1, 1, 21);
 }
 RT_DEV float coord_of(uint32_t hi21, uint32_t, float) { return (float)hi21 * 0x1.0p-20f - 1.0f; }
 // gen_range(-1.0..1.0) on the 52-bit mantissa m = hi << 31 | lo: (m * 2^-52) * 2 + -1.  Every step of that is exact (m has 52
@@ -341,7 +360,7 @@ template <class R, class S> RT_DEV V3<R> random_in_unit_sphere(const S& s) { ret
 // RELAXED (double precision, small-scene presets): the refined reciprocal square root (2 ulp) instead of sqrt then divide.
 template <bool RELAXED, class S> RT_DEV V3<double> random_unit_vector(const S& s, double) {
   const V3<double> p = random_in_unit_sphere<double>(s);
-  if constexpr (RELAXED) return rsq_refined(length_squared(p)) * p;
+  if constexpr (RELAXED) return rsq_one_step(length_squared(p)) * p;
   else return unit_vector(p);
 }
 template <bool RELAXED, class S> RT_DEV V3<float> random_unit_vector(const S& s, float) {

@@ -8,6 +8,8 @@
 // cannot reproduce is a stale (u, v) left behind by an earlier candidate when the winner is a shape that does not write
 // them (moving sphere, medium): presets containing those shapes together with (u, v)-reading textures use the eager walk.
 #pragma once
+#include <type_traits>
+
 #include "device_trace.h"
 
 #ifdef RT_STAMPS
@@ -301,19 +303,20 @@ RT_DEV bool in_closed(float x, float lo, float hi) { return __builtin_amdgcn_fme
 RT_DEV bool in_closed(double x, double lo, double hi) { return (x >= lo) & (x <= hi); }
 
 // Reciprocal of a direction component for the flat walk.  Single precision: the hardware estimate (1 ulp).  Double precision: the
-// quotient 1/d, which is what Aabb::hit multiplies by (src/aabb.rs:33), from the refined hardware estimate.
+// hardware estimate and one Newton step (0.6 ulp on average and 11 at most from the quotient 1/d that Aabb::hit multiplies by,
+// src/aabb.rs:33); a plane distance formed with it is within a dozen ulp of the reference's quotient (k - o) / d.
 RT_DEV float flat_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #ifdef RT_EXP_IEEE_RCP
 RT_DEV double flat_rcp(double x) { return 1.0 / x; }
 #else
-RT_DEV double flat_rcp(double x) { return rcp_refined(x); }
+RT_DEV double flat_rcp(double x) { return rcp_one_step(x); }
 #endif
 RT_DEV float next_up(float x) { return nextafterf(x, Lim<float>::inf()); }
 RT_DEV double next_up(double x) { return nextafter(x, Lim<double>::inf()); }
 
 // Distances along the ray as (plane - origin) * (1 / direction) in both precisions: the flat walk forms every plane distance the
 // way the reference's box test does (src/aabb.rs:33-35).  Against the quotient (k - o) / d of src/aarect.rs:89 that is one more
-// rounding, i.e. at most 1 ulp of t.
+// rounding and the reciprocal's own error (double precision: a dozen ulp at most), parts in 10^15 of t.
 template <class R> struct RayRcp {
   V3<R> inv;
   RT_DEV explicit RayRcp(V3<R> dir) : inv(flat_rcp(dir.x), flat_rcp(dir.y), flat_rcp(dir.z)) {}
@@ -355,10 +358,11 @@ RT_DEV bool box_slab_t(const DShape<R>& s, const Ray<R>& ray, const RayRcp<R>& r
   const R nz = min_plain(z0, z1), fz = max_plain(z0, z1);
   const R tn = max_plain(max_plain(nx, ny), nz);
   const R tf = min_plain(min_plain(fx, fy), fz);
-  // sides: 0 z=hi, 1 z=lo, 2 y=hi, 3 y=lo, 4 x=hi, 5 x=lo; the near plane of an axis is lo when the ray moves up that axis
-  const int px = ray.d.x > (R)0 ? 1 : 0, py = ray.d.y > (R)0 ? 1 : 0, pz = ray.d.z > (R)0 ? 1 : 0;
-  const int near_side = nx == tn ? 4 + px : (ny == tn ? 2 + py : pz);
-  const int far_side = fx == tf ? 5 - px : (fy == tf ? 3 - py : 1 - pz);
+  // sides: 0 z=hi, 1 z=lo, 2 y=hi, 3 y=lo, 4 x=hi, 5 x=lo; the near plane of an axis is lo when the ray moves up that axis, and
+  // its far plane is the other one of the pair (the code with its lowest bit flipped)
+  const int cx = ray.d.x > (R)0 ? 5 : 4, cy = ray.d.y > (R)0 ? 3 : 2, cz = ray.d.z > (R)0 ? 1 : 0;
+  const int near_side = nx == tn ? cx : (ny == tn ? cy : cz);
+  const int far_side = (fx == tf ? cx : (fy == tf ? cy : cz)) ^ 1;
   const bool cross = tn <= tf;
   const bool enter_ok = cross & in_closed(tn, t_min, t_max) & (near_side != self_side);
   const bool leave_ok = cross & in_closed(tf, t_min, t_max) & (far_side != self_side);
@@ -382,13 +386,14 @@ template <class R> RT_DEV bool box_slab_span(const DShape<R>& s, const Ray<R>& r
 // anyway, so the inner box tests and the per-lane position in the tree are pure overhead here.
 //   Double precision: the leaves in the order the tree visits them, so that among exactly coincident surfaces (a box standing on
 //   the floor) the same one is reported as by the reference's walk; a box is three slabs, and plane distances are
-//   (plane - origin) * (1 / direction) (see RayRcp), so t is within 1 ulp of the reference's quotient.
+//   (plane - origin) * (1 / direction) (see RayRcp), so t is within a dozen ulp of the reference's quotient.
 //   Single precision: plain rectangles first, grouped by axis, then the other leaves in visiting order.
 template <class R, class C>
 RT_DEV bool traverse_flat(const SceneView<R, C>& sv, int start, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org) {
   const RayRcp<R> ri(ray.d);
   R closest = t_max;
-  int best_leaf = -1, best_side = -1;
+  // the winning candidate so far as one word, (leaf << 3) | (side + 1), -1 = none: one select per accepted test instead of two
+  int best = -1;
   // No box test at all, not even the root's: a ray that starts on a surface starts inside the root box, and camera rays that miss
   // it share their wave with lanes at other bounces, so the early out would never be taken by a whole wave.
   (void)start;
@@ -398,24 +403,18 @@ RT_DEV bool traverse_flat(const SceneView<R, C>& sv, int start, const Ray<R>& ra
     if constexpr (Guard<R>::on) {
       // plain rectangles, one list per constant axis: one record fetch and a dozen vector instructions each
       const FlatRect* fr = sv.frect;
-      for (uint32_t k = 0; k < sv.n_frect[0]; ++k, ++fr) {
-        const FlatRect r = load_uniform(fr);
-        R t;
-        const bool ok = rect_fast<0>(r.a0, r.a1, r.b0, r.b1, r.k, ray, ri, t_min, closest, t) & (org_leaf != r.obj);
-        closest = ok ? t : closest; best_leaf = ok ? r.obj : best_leaf; best_side = ok ? -1 : best_side;
-      }
-      for (uint32_t k = 0; k < sv.n_frect[1]; ++k, ++fr) {
-        const FlatRect r = load_uniform(fr);
-        R t;
-        const bool ok = rect_fast<1>(r.a0, r.a1, r.b0, r.b1, r.k, ray, ri, t_min, closest, t) & (org_leaf != r.obj);
-        closest = ok ? t : closest; best_leaf = ok ? r.obj : best_leaf; best_side = ok ? -1 : best_side;
-      }
-      for (uint32_t k = 0; k < sv.n_frect[2]; ++k, ++fr) {
-        const FlatRect r = load_uniform(fr);
-        R t;
-        const bool ok = rect_fast<2>(r.a0, r.a1, r.b0, r.b1, r.k, ray, ri, t_min, closest, t) & (org_leaf != r.obj);
-        closest = ok ? t : closest; best_leaf = ok ? r.obj : best_leaf; best_side = ok ? -1 : best_side;
-      }
+      auto rect_list = [&](auto axis_tag, uint32_t n) {
+        constexpr int AXIS = decltype(axis_tag)::value;
+        for (uint32_t k = 0; k < n; ++k, ++fr) {
+          const FlatRect r = load_uniform(fr);
+          R t;
+          const bool ok = rect_fast<AXIS>(r.a0, r.a1, r.b0, r.b1, r.k, ray, ri, t_min, closest, t) & (org_leaf != r.obj);
+          closest = ok ? t : closest; best = ok ? (r.obj << 3) : best;
+        }
+      };
+      rect_list(std::integral_constant<int, 0>{}, sv.n_frect[0]);
+      rect_list(std::integral_constant<int, 1>{}, sv.n_frect[1]);
+      rect_list(std::integral_constant<int, 2>{}, sv.n_frect[2]);
     }
     for (uint32_t k = 0; k < sv.n_flat; ++k) {
       const FlatLeaf<R> fl = load_uniform(sv.flat + k);
@@ -511,12 +510,12 @@ RT_DEV bool traverse_flat(const SceneView<R, C>& sv, int start, const Ray<R>& ra
         if (plain) shape_test(local, rl);
       }
       closest = ok ? t : closest;
-      best_leaf = ok ? obj : best_leaf;
-      best_side = ok ? side : best_side;
+      best = ok ? ((obj << 3) | (side + 1)) : best;
     }
   }
   RT_STAMP_IN(media, 4);
-  if (best_leaf < 0) return false;
+  if (best < 0) return false;
+  const int best_leaf = best >> 3, best_side = (best & 7) - 1;
   if constexpr (!C::has(F_UV) && !C::has(F_SPHERE) && !C::has(F_MOVING)) {
     // every surface here is a planar side: its record comes from the table of sides.  The normal goes through the reference's
     // chain of set_face_normal calls - shape, RotateY (which pairs the rotated normal with the UNrotated-frame direction,
