@@ -109,7 +109,11 @@ RT_DEV bool shade_hit(const SceneView<R, C>& sv, const Ray<R>& ray_in, Rec<R>& r
   switch (m.tag) {
     case MAT_LAMBERTIAN: {  // src/material.rs:43-57
       V3<R> dir = rec.n + random_unit_vector<R, C::relaxed()>(rng);
-      if (near_zero(dir)) dir = rec.n;
+      // practically never true: a branch the whole wave skips instead of three selects in every lane
+      const bool degenerate = near_zero(dir);
+      if (__ballot(degenerate) != 0ull) {
+        if (degenerate) dir = rec.n;
+      }
       scattered.d = dir;
       attenuation = material_color<R, C>(sv, m, rec);
       return true;
@@ -177,10 +181,9 @@ template <bool RELAXED> RT_DEV float jitter_coord(uint32_t i, float u, uint32_t 
 // Primary ray of (pixel, sample): src/render.rs:230-234 then Camera::get_ray (src/camera.rs:62-72).
 // pixel = y * W + x with y counted from the top row; the reference's j is H - 1 - y.
 // `rng` is the camera stream of (pixel, sample).
+// `y`, `i`: the pixel's row (from the top) and column.
 template <class R, bool RELAXED, class S>
-RT_DEV Ray<R> primary_ray(const DCamera<R>& cam, uint32_t W, uint32_t H, uint32_t pixel, const S& rng) {
-  uint32_t y, i;
-  pixel_row_col(pixel, W, y, i);
+RT_DEV Ray<R> primary_ray_at(const DCamera<R>& cam, uint32_t W, uint32_t H, uint32_t y, uint32_t i, const S& rng) {
   uint32_t j = H - 1u - y;
   const Block<R> jitter(rng, 0u);
   R u_rand = jitter.u01(0);
@@ -200,6 +203,12 @@ RT_DEV Ray<R> primary_ray(const DCamera<R>& cam, uint32_t W, uint32_t H, uint32_
   }
   ray.time = jitter.range(2, cam.t_open, cam.t_close);
   return ray;
+}
+template <class R, bool RELAXED, class S>
+RT_DEV Ray<R> primary_ray(const DCamera<R>& cam, uint32_t W, uint32_t H, uint32_t pixel, const S& rng) {
+  uint32_t y, i;
+  pixel_row_col(pixel, W, y, i);
+  return primary_ray_at<R, RELAXED>(cam, W, H, y, i, rng);
 }
 template <class R, bool RELAXED = false>
 RT_DEV Ray<R> primary_ray(const DCamera<R>& cam, uint32_t W, uint32_t H, uint32_t pixel, uint32_t sample, uint64_t seed) {

@@ -266,13 +266,15 @@ constexpr uint32_t kBlocksPerTurn = 2, kBlocksPerRestart = RT_BLOCKS_PER_RESTART
 // sample `sample` (path index = sample * n_pixels + pixel, kept as the pair so that no lane ever divides).
 template <class R> struct PathFeeder {
   uint32_t left = 0, pixel = 0, sample = 0;
+  uint32_t row = 0, col = 0;  // of `pixel` (row counted from the top): carried along so that no lane has to split a pixel index
   bool exhausted = false;  // the global cursor has passed total_paths
 
   // Gives every lane with `!active` a new path while there are any; lanes that receive one become active with bounce = 0.
   // MAKE_RAY = false leaves st.ray for the caller to fill in.
   // FIXED_GRAB: the grab is kPathGrab (large frames), a constant the compiler folds, instead of fp.path_grab.
+  // `px_row`, `px_col`: row and column of the pixel a lane receives.
   template <bool MAKE_RAY, bool FIXED_GRAB> RT_DEV void refill(const DeviceScene<R>& sc, const FrameParams& fp, unsigned long long total_paths, unsigned long long* path_cursor,
-                     PathState<R>& st, uint32_t& bounce, bool& active) {
+                     PathState<R>& st, uint32_t& bounce, bool& active, uint32_t& px_row, uint32_t& px_col) {
     const uint32_t lane = threadIdx.x & 63u;
     unsigned long long dead = __ballot(!active);
     while (dead != 0ull && !exhausted) {
@@ -288,6 +290,8 @@ template <class R> struct PathFeeder {
         left = (uint32_t)(e - b);
         sample = (uint32_t)(b / fp.n_pixels);
         pixel = (uint32_t)(b - (unsigned long long)sample * fp.n_pixels);
+        row = pixel / fp.width;
+        col = pixel - row * fp.width;
       }
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
       const uint32_t n_dead = (uint32_t)__popcll(dead);
@@ -296,6 +300,14 @@ template <class R> struct PathFeeder {
       n_take = n_take < row_left ? n_take : row_left;
       if (!active && rank < n_take) {
         st.pixel = pixel + rank;
+        if (fp.width >= 64u) {  // the lanes of one step span at most two rows
+          const uint32_t c = col + rank;
+          const bool wrap = c >= fp.width;
+          px_col = wrap ? c - fp.width : c;
+          px_row = row + (wrap ? 1u : 0u);
+        } else {
+          pixel_row_col(st.pixel, fp.width, px_row, px_col);
+        }
         st.sample = fp.sample_base + sample;
         if constexpr (MAKE_RAY) st.ray = primary_ray<R>(sc.camera, fp.width, fp.height, st.pixel, st.sample, fp.seed);
         st.thr = V3<R>((R)1, (R)1, (R)1);
@@ -305,7 +317,9 @@ template <class R> struct PathFeeder {
       }
       left -= n_take;
       pixel += n_take;
-      if (pixel == fp.n_pixels) { pixel = 0u; sample += 1u; }
+      col += n_take;
+      while (col >= fp.width) { col -= fp.width; row += 1u; }
+      if (pixel == fp.n_pixels) { pixel = 0u; sample += 1u; row = 0u; col = 0u; }
       dead = __ballot(!active);
     }
   }
@@ -341,6 +355,7 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? (sizeof(R) == 8 ? RT_NESTED
   Rec<R> rec;
   V3<R> sum((R)0, (R)0, (R)0);  // radiance of the samples of the lane's chunk so far
   uint32_t more = 0;            // samples of the chunk still to start after the current one
+  uint32_t px_row = 0, px_col = 0;  // row / column of the lane's pixel, set when the lane receives a path
   RT_STAMP_INIT();
   // One turn: paths that end at their last hit are closed - their lanes go on with the next sample of their chunk or, the chunk
   // done, add its sum to the pixel and take a new chunk - then ONE evaluation of Philox serves the scatter draw of the continuing
@@ -388,7 +403,7 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? (sizeof(R) == 8 ? RT_NESTED
     RT_STAMP(6);
     if constexpr (CHUNKED) {
       const bool was_active = active;
-      feeder.template refill<false, FIXED_GRAB>(sc, fp, total_paths, path_cursor, st, bounce, active);
+      feeder.template refill<false, FIXED_GRAB>(sc, fp, total_paths, path_cursor, st, bounce, active, px_row, px_col);
       if (active && !was_active) {  // a new chunk: the feeder's "sample" is the chunk's index
         const uint32_t first = (st.sample - fp.sample_base) * fp.chunk;
         const uint32_t n = fp.n_samples - first < fp.chunk ? fp.n_samples - first : fp.chunk;
@@ -397,7 +412,7 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? (sizeof(R) == 8 ? RT_NESTED
         sum = V3<R>((R)0, (R)0, (R)0);
       }
     } else {
-      feeder.template refill<false, FIXED_GRAB>(sc, fp, total_paths, path_cursor, st, bounce, active);
+      feeder.template refill<false, FIXED_GRAB>(sc, fp, total_paths, path_cursor, st, bounce, active, px_row, px_col);
     }
     RT_STAMP(0);
     if (__ballot(active) == 0ull) break;
@@ -418,7 +433,7 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? (sizeof(R) == 8 ? RT_NESTED
       }
     }
     RT_STAMP(2);
-    if (!to_scatter && active) st.ray = primary_ray<R, C::relaxed()>(sv.camera(), fp.width, fp.height, st.pixel, rng);
+    if (!to_scatter && active) st.ray = primary_ray_at<R, C::relaxed()>(sv.camera(), fp.width, fp.height, px_row, px_col, rng);
     RT_STAMP(1);
     // an absorbed path (a metal's scattered ray below the surface, src/material.rs:88-90) ends here: it sits out this trace as a
     // miss that adds nothing, and the next turn closes it like any other ended path
@@ -498,6 +513,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
   uint32_t bounce = 0;
   unsigned long long n_rays = 0;
   PathState<R> st;
+  uint32_t px_row = 0, px_col = 0;  // row / column of the lane's pixel, set when the lane receives a path
   // walk state of the lane's current ray
   constexpr bool WIDE = C::walk == WALK_LANE_WIDE;
   int i = LINK_END;     // entry to look at next; LINK_END = no walk in progress.  Four-wide walk: 0 while `wl` holds a walk
@@ -558,7 +574,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
           to_scatter = true;
         }
       }
-      feeder.template refill<false, FIXED_GRAB>(sc, fp, total_paths, path_cursor, st, bounce, active);
+      feeder.template refill<false, FIXED_GRAB>(sc, fp, total_paths, path_cursor, st, bounce, active, px_row, px_col);
       if (i < 0 && active) {  // one Philox pass: scatter draw of the continuing lanes, pixel jitter of the new ones
         const PrimedStream rng(Stream(fp.seed, st.pixel, st.sample, bounce, to_scatter ? STAGE_SCATTER : STAGE_CAMERA), to_scatter ? resume : 0u, kBlocksPerRestart);
         if (to_scatter) {
@@ -574,7 +590,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
             active = alive;
           }
         } else {
-          st.ray = primary_ray<R, C::relaxed()>(sv.camera(), fp.width, fp.height, st.pixel, rng);
+          st.ray = primary_ray_at<R, C::relaxed()>(sv.camera(), fp.width, fp.height, px_row, px_col, rng);
         }
       }
       const bool start = i < 0 && active && resume == 0u;
