@@ -223,7 +223,7 @@ def main():
         # per-lane walks of trees that do not fit on chip: what a closest-hit query costs on the tree THIS precision walks (the f64
         # kernels walk the reference's tree, the f32 kernels the library's own), measured on the device over the rays of 8192 paths
         walk = None
-        if rank == 0 and stats and stats[-1]["scene_in_lds"] in (4, 6, 8, 9, 10) and n_objects >= 100_000:
+        if rank == 0 and stats and stats[-1]["scene_in_lds"] in (4, 6, 8, 9, 10, 11, 12) and n_objects >= 100_000:
             walk = ctx.walk_cost(prec, n_paths=8192, seed=1)
         return {"name": name, "walk": walk, "elapsed": elapsed_max, "rays": rays, "rays_all": rays_all, "kernel_ms": kernel_ms, "launches": launches,
                 "stats": stats, "rgb": None if rgb is None else rgb.copy(), "accum": accum, "split": split, "per_rank": per_rank}
@@ -255,7 +255,7 @@ def main():
         # bytes the algorithm has to move per ray: the queue pipelines read and write one queue entry per ray; the persistent
         # pipeline keeps paths in registers and only adds finished radiance terms to the pixel sums (4 values per path)
         qb = (4 * (8 if name == "f64" else 4)) / rays_per_sample if persistent else QUEUE_BYTES_PER_RAY[name]
-        kernel = (("k_paths_stepwise" if stats[-1]["scene_in_lds"] in (5, 6, 7, 8, 9, 10) else "k_paths_persistent") if persistent
+        kernel = (("k_paths_stepwise" if stats[-1]["scene_in_lds"] in (5, 6, 7, 8, 9, 10, 11, 12) else "k_paths_persistent") if persistent
                   else ("k_bounce_fused" if args.pipeline == "fused" else "k_trace+k_shade"))
         secs = leg["kernel_ms"] * 1e-3
         valu = {"bound": "valu", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "flops_per_ray": fpr}

@@ -187,9 +187,11 @@ typedef struct rt_stats {
   double gen_kernel_ms;        /* HIP-event time of the primary-ray kernels */
   uint64_t passes;
   uint32_t lds_bytes;          /* LDS used per workgroup by the bounce kernel */
-  uint32_t scene_in_lds;       /* kernel preset the scene selected: 0 boxes, 1 smoke, 2 spheres, 3 all (scene in LDS), 4 all (top links in LDS), 5/6 spheres-only lane walk (LDS / top links), 7/8 all without nested trees (images whose nested trees were dissolved or spliced), 9/10 spheres-only / all without nested trees on the four-wide form of the library's own tree */
+  uint32_t scene_in_lds;       /* kernel preset the scene selected: 0 boxes, 1 smoke, 2 spheres, 3 all (scene in LDS), 4 all (top links in LDS), 5/6 spheres-only lane walk (LDS / top links), 7/8 all without nested trees (images whose nested trees were dissolved or spliced), 9/10 spheres-only / all without nested trees on the four-wide form of the library's own tree, 11/12 the same with the reference's leaf arithmetic and tie rule (the double-precision default) */
   uint32_t kernel_variant;     /* PERSISTENT pipeline: which instantiation of the path kernel ran, RT_VARIANT_* bits */
   uint32_t pad;
+  uint64_t paths_redone;       /* double precision on the library's own tree: paths on which two different surfaces lay at exactly the
+                                  same distance, traced a second time by the list walk in the reference's order (src/bvh.rs:108-119) */
 } rt_stats;
 #define RT_VARIANT_FIXED_GRAB 1u       /* paths handed out in constant grabs of 2048 per wave (large frames) */
 #define RT_VARIANT_CHUNKED 2u          /* a lane sums up to 16 samples of one pixel before its one atomic add (cheap bright paths) */

@@ -167,13 +167,6 @@ class FastTreeBuilder {
     }
     return g;  // 26 values at most; the rest stays zero
   }
-  // The padded box of a bare shape as the library's own tree uses it (no ray whose shape test succeeds misses it), false for
-  // objects it has no such box for: nested trees, and spheres of negative radius, whose reach the reference's boxes decide.
-  bool tight_box(int o, Box3d& out) const {
-    if ((s_.objects[o].flags & RT_OBJ_SUB_BVH) || has_guard(o)) return false;
-    out = object_box(o);
-    return true;
-  }
   // Objects that may stand in for an exact copy of themselves: bare or wrapped shapes, but no medium (it draws random numbers per
   // visit), no nested tree, and no sphere of negative radius (what reaches it is decided by the boxes around each copy).
   bool copy_eligible(int o) const {
@@ -588,137 +581,5 @@ class FastTreeBuilder {
     mark("threaded list");
   }
 };
-
-// The four-wide form of a tree given as a threaded list (the caller's tree as the double-precision kernels walk it: the
-// reference's nodes, boxes and order, exact copies left out).  A node of the list with its box becomes a slot of a wide node; a
-// leaf takes the box of the list entry above it, which is the last box the list walk tests before it reaches the leaf, and the
-// boxes of the entries folded away in between contain those below them, so a leaf is tested by exactly the rays whose list walk
-// could accept it: those that pass every box above it with a distance below the closest hit so far (`tight`: and that pass the
-// padded boxes of the shapes themselves, which every ray does whose shape test can succeed).  What the wide walk changes
-// is the order of the tests, which decides nothing but exact ties - so this form is only built for scenes of spheres, where two
-// different surfaces never lie at the same distance along a ray (exact copies are reduced to the one the reference reports).
-// Returns the stack entries the deepest walk can hold.
-inline int wide_from_links(const std::vector<TmpLink>& links, int root, std::vector<WideTmp>& wide, const FastTreeBuilder* tight = nullptr,
-                           std::vector<uint32_t>* pre = nullptr) {
-  wide.clear();
-  if (pre) pre->clear();
-  if (root < 0 || (links[(size_t)root].hit & LEAF_FLAG)) return 0;
-  // `pre`: shapes as large as the scene leave the tree and are tested ahead of the walk (FastTreeBuilder::wide_pre), which the
-  // caller may only ask for where the order of the tests decides nothing
-  if (pre && tight && links.size() > 16 && !std::getenv("RTAMD_NO_PRE_LEAVES")) {
-    Box3d all, own;
-    all.reset();
-    for (const TmpLink& l : links)
-      if ((l.hit & LEAF_FLAG) && tight->tight_box((int)(l.hit & LEAF_INDEX_MASK), own)) all.grow(own);
-    for (const TmpLink& l : links)
-      if ((l.hit & LEAF_FLAG) && pre->size() < kWidePre && tight->tight_box((int)(l.hit & LEAF_INDEX_MASK), own) && own.area() >= 0.5 * all.area() &&
-          std::find(pre->begin(), pre->end(), l.hit) == pre->end())
-        pre->push_back(l.hit);
-  }
-  auto is_pre = [&](uint32_t word) { return pre && std::find(pre->begin(), pre->end(), word) != pre->end(); };
-  struct Item { int entry; int box_of; int level; };  // a list entry, the inner entry whose box it is tested with (itself when it is one), levels below the wide node
-  auto children = [&](int i, int level, std::vector<Item>& out) {
-    const TmpLink& l = links[(size_t)i];
-    for (int c = (int)l.hit; c != l.miss && c != i && c >= 0; c = links[(size_t)c].miss) {
-      if ((links[(size_t)c].hit & LEAF_FLAG) && is_pre(links[(size_t)c].hit)) continue;
-      out.push_back(Item{c, (links[(size_t)c].hit & LEAF_FLAG) ? i : c, level});
-    }
-  };
-  auto area = [&](int i) {
-    const TmpLink& l = links[(size_t)i];
-    const double d[3] = {l.bmax[0] - l.bmin[0], l.bmax[1] - l.bmin[1], l.bmax[2] - l.bmin[2]};
-    return (d[0] < 0 || d[1] < 0 || d[2] < 0) ? 0.0 : 2.0 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
-  };
-  // What the shapes below an entry can occupy: the union of their padded boxes (everything, when a shape below has none).  A ray
-  // that misses it fails every shape test below the entry, so the entry's box may be cut down to the overlap of the two - the
-  // reference's boxes are wider than that wherever a copy that is no longer walked, or a loose median split, stretched them.
-  const double inf = std::numeric_limits<double>::infinity();
-  std::vector<Box3d> reach;
-  if (tight) {
-    reach.resize(links.size());
-    std::vector<Item> below;
-    for (size_t i = links.size(); i-- > 0;) {  // children come after their parent in the list as it is built
-      Box3d& r = reach[i];
-      if (links[i].hit & LEAF_FLAG) {
-        if (!tight->tight_box((int)(links[i].hit & LEAF_INDEX_MASK), r))
-          for (int a = 0; a < 3; ++a) { r.mn[a] = -inf; r.mx[a] = inf; }
-        continue;
-      }
-      r.reset();
-      below.clear();
-      children((int)i, 0, below);
-      for (const Item& c : below) {
-        if (c.entry <= (int)i) { for (int a = 0; a < 3; ++a) { r.mn[a] = -inf; r.mx[a] = inf; } break; }  // not the order assumed: no cut
-        r.grow(reach[(size_t)c.entry]);
-      }
-    }
-  }
-  wide.emplace_back();
-  std::vector<int> queue{root};
-  std::vector<Item> items, grown;
-  for (size_t k = 0; k < queue.size(); ++k) {
-    items.clear();
-    children(queue[k], 1, items);
-    for (;;) {
-      // the entry nearest to the wide node first (the reference's median splits are balanced: folding level by level keeps the wide
-      // tree at half the depth, which is what bounds the walk's stack), the larger box among those
-      int pick = -1;
-      double best = -1.0;
-      for (size_t j = 0; j < items.size(); ++j) {
-        if (links[(size_t)items[j].entry].hit & LEAF_FLAG) continue;
-        grown.clear();
-        children(items[j].entry, items[j].level + 1, grown);
-        if (items.size() - 1 + grown.size() > 4) continue;
-        const double a = grown.empty() ? 1e300 : area(items[j].entry);  // an entry with nothing below it just goes away
-        if (pick < 0 || items[j].level < items[(size_t)pick].level || (items[j].level == items[(size_t)pick].level && a > best)) { best = a; pick = (int)j; }
-      }
-      if (pick < 0) break;
-      grown.clear();
-      children(items[(size_t)pick].entry, items[(size_t)pick].level + 1, grown);
-      items.erase(items.begin() + pick);
-      items.insert(items.end(), grown.begin(), grown.end());
-    }
-    WideTmp w{};
-    for (int c = 0; c < 4; ++c) {
-      w.child[c] = kWideNone;
-      for (int a = 0; a < 3; ++a) w.lo[c][a] = w.hi[c][a] = std::numeric_limits<double>::infinity();
-    }
-    for (size_t j = 0; j < items.size(); ++j) {
-      const TmpLink& b = links[(size_t)items[j].box_of];
-      for (int a = 0; a < 3; ++a) { w.lo[j][a] = b.bmin[a]; w.hi[j][a] = b.bmax[a]; }
-      const TmpLink& e = links[(size_t)items[j].entry];
-      if (tight) {  // ... cut down to what the shapes below can occupy, where the two overlap
-        const Box3d& own = reach[(size_t)items[j].entry];
-        double lo[3], hi[3];
-        bool overlap = true;
-        for (int a = 0; a < 3; ++a) {
-          lo[a] = std::max(w.lo[j][a], own.mn[a]); hi[a] = std::min(w.hi[j][a], own.mx[a]);
-          overlap = overlap && lo[a] <= hi[a];
-        }
-        if (overlap)
-          for (int a = 0; a < 3; ++a) { w.lo[j][a] = lo[a]; w.hi[j][a] = hi[a]; }
-      }
-      if (e.hit & LEAF_FLAG) {
-        w.child[j] = e.hit;
-      } else {
-        w.child[j] = (uint32_t)wide.size();
-        wide.emplace_back();
-        queue.push_back(items[j].entry);
-      }
-    }
-    wide[k] = w;
-  }
-  std::vector<int> need(wide.size(), 0);
-  for (size_t k = wide.size(); k-- > 0;) {
-    int m = 0, below = 0;
-    for (int c = 0; c < 4; ++c) {
-      if (wide[k].child[c] == kWideNone) continue;
-      ++m;
-      if (!(wide[k].child[c] & LEAF_FLAG)) below = std::max(below, need[(size_t)wide[k].child[c]]);
-    }
-    need[k] = std::max(0, m - 1) + below;
-  }
-  return need[0];
-}
 
 }  // namespace rti

@@ -191,6 +191,11 @@ enum : uint32_t {
   F_METAL = 1u << 11, F_DIELECTRIC = 1u << 12,
   F_GRADIENT = 1u << 13,  // gradient background
   F_ALL = (1u << 14) - 1u,
+  // Not a part of the scene grammar: the four-wide walk standing in for the reference's own walk in double precision.  Leaf tests
+  // are the reference's expressions (a box is its six rectangles, with true quotients), and a ray on which two different leaves
+  // report exactly the same distance - the one case in which the order of the tests decides what is reported - is flagged and
+  // traced once more by the list walk in the reference's order.
+  F_EXACT = 1u << 14,
 };
 // WALK_UNIFORM: the scene has few leaves (<= kFlatMaxLeaves).  Every wave steps through the list of leaves in the tree's visiting
 //   order with a wave-uniform index, so shape and object data arrive through scalar loads and live in scalar registers; every
@@ -239,11 +244,14 @@ using CfgBallsLds = Cfg<P_BALLS, WALK_LANE_LDS_ALL>;
 using CfgBallsTop = Cfg<P_BALLS, WALK_LANE_LDS_TOP>;
 using CfgBallsWide = Cfg<P_BALLS, WALK_LANE_WIDE>;
 using CfgFlatAllWide = Cfg<F_ALL & ~F_NESTED, WALK_LANE_WIDE>;
+using CfgBallsWideExact = Cfg<P_BALLS | F_EXACT, WALK_LANE_WIDE>;
+using CfgFlatAllWideExact = Cfg<(F_ALL & ~F_NESTED) | F_EXACT, WALK_LANE_WIDE>;
 enum {
   PRESET_BOXES = 0, PRESET_SMOKE = 1, PRESET_SPHERES = 2, PRESET_ALL_LDS = 3, PRESET_ALL_TOP = 4, PRESET_BALLS_LDS = 5, PRESET_BALLS_TOP = 6,
   PRESET_FLATALL_LDS = 7, PRESET_FLATALL_TOP = 8,  // images whose nested trees were dissolved (the library's own tree)
   PRESET_BALLS_WIDE = 9, PRESET_FLATALL_WIDE = 10,  // the library's own tree in its four-wide form
-  PRESET_COUNT = 11
+  PRESET_BALLS_WIDE_EXACT = 11, PRESET_FLATALL_WIDE_EXACT = 12,  // ... with the reference's leaf arithmetic and tie rule (double precision)
+  PRESET_COUNT = 13
 };
 
 // Read-only record at a wave-uniform address in global memory that no kernel writes (the scene blob): loaded through

@@ -90,8 +90,8 @@ RT_DEV bool shape_t(const DShape<R>& s, const Ray<R>& ray, const RayInv<R>& ri, 
     case SH_RECT_XY: if constexpr (C::has(F_RECT)) { if (!self && rect_t<R, 2>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], ray, ri, t_min, t_max, t_out)) { side_out = -1; hit = true; } } break;
     case SH_RECT_XZ: if constexpr (C::has(F_RECT)) { if (!self && rect_t<R, 1>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], ray, ri, t_min, t_max, t_out)) { side_out = -1; hit = true; } } break;
     case SH_RECT_YZ: if constexpr (C::has(F_RECT)) { if (!self && rect_t<R, 0>(s.p[0], s.p[1], s.p[2], s.p[3], s.p[4], ray, ri, t_min, t_max, t_out)) { side_out = -1; hit = true; } } break;
-    case SH_BOX: if constexpr (C::has(F_BOX) && (sizeof(R) == sizeof(float) || C::walk == WALK_LANE_WIDE)) {
-      // single precision, and double precision on the library's own tree (compared with the reference by tolerance): the six sides as
+    case SH_BOX: if constexpr (C::has(F_BOX) && (sizeof(R) == sizeof(float) || (C::walk == WALK_LANE_WIDE && !C::has(F_EXACT)))) {
+      // single precision, and double precision where the walk is compared with the reference by tolerance: the six sides as
       // three slabs, with the reference's side numbering and tie order - a third of the instructions of six rectangle tests, and in
       // double precision no division
       hit = box_slab_t<R>(s, ray, RayRcp<R>(ri.inv, 0), t_min, t_max, self ? self_side : -2, t_out, side_out);
@@ -697,8 +697,12 @@ RT_DEV bool traverse_lane_deferred(const SceneView<float, C>& sv, int start, con
 
 // The four-wide walk of one ray from start to end (the path kernels step through it instead: k_paths_stepwise), records built as
 // k_paths_stepwise builds them (Cfg::defer_records).
+// `tie` (F_EXACT configurations): set when two different leaves report exactly the same distance, the one case in which the order
+// of the tests decides what is reported (src/bvh.rs:108-119 gives it to the leaf its walk tests last, if its boxes let it get
+// there); the caller then asks the list walk, which keeps the reference's order.
 template <class R, class C>
-RT_DEV bool traverse_wide(const SceneView<R, C>& sv, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org, Visits* tally) {
+RT_DEV bool traverse_wide(const SceneView<R, C>& sv, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org, Visits* tally,
+                          bool* tie = nullptr) {
   constexpr bool DEFER = C::template defer_records<R>();
   const LaneBoxTest<R> box(ray);
   WideLane<R> w;
@@ -708,16 +712,23 @@ RT_DEV bool traverse_wide(const SceneView<R, C>& sv, const Ray<R>& ray, R t_min,
   int best_leaf = -1, best_side = -1;
   auto test_leaf = [&](uint32_t word) {
     if (tally) ++tally->leaves;
+    const int leaf = (int)(word & LEAF_INDEX_MASK);
     if constexpr (DEFER) {
       RayInv<R> ri(ray.d);
       ri.inv = box.inv;
       R t;
       int side;
       if (leaf_t<R, C>(sv, word, ray, ri, t_min, closest, media, org, t, side, visit_bit(word, 0))) {
-        closest = t; best_leaf = (int)(word & LEAF_INDEX_MASK); best_side = side;
+        if (tie && best_leaf >= 0 && best_leaf != leaf && t == closest) *tie = true;
+        closest = t; best_leaf = leaf; best_side = side;
       }
     } else {
-      if (leaf_hit<R, C, 0>(sv, word, ray, t_min, closest, rec, media, org)) { closest = rec.t; any = true; }
+      const int prev_leaf = rec.leaf;
+      const R prev_t = closest;
+      if (leaf_hit<R, C, 0>(sv, word, ray, t_min, closest, rec, media, org)) {
+        if (tie && any && rec.leaf >= 0 && prev_leaf >= 0 && prev_leaf != rec.leaf && rec.t == prev_t) *tie = true;
+        closest = rec.t; any = true;
+      }
     }
   };
   for (uint32_t k = 0; k < sv.n_pre; ++k) test_leaf(sv.pre[k]);  // objects as large as the scene, kept outside the tree
@@ -746,7 +757,15 @@ RT_DEV bool closest_hit(const SceneView<R, C>& sv, int root, const Ray<R>& ray, 
     if (tally) tally->leaves += sv.n_flat + sv.n_frect[0] + sv.n_frect[1] + sv.n_frect[2];  // every leaf, no box
     return traverse_flat<R, C>(sv, root, ray, t_min, t_max, rec, media, org);
   } else if constexpr (C::walk == WALK_LANE_WIDE) {
-    return traverse_wide<R, C>(sv, ray, t_min, t_max, rec, media, org, tally);
+    if constexpr (C::has(F_EXACT) && sizeof(R) == sizeof(double)) {
+      bool tie = false;
+      const bool hit = traverse_wide<R, C>(sv, ray, t_min, t_max, rec, media, org, tally, &tie);
+      if (!tie) return hit;
+      rec = Rec<R>();
+      return traverse_lane<R, C, 0>(sv, root, ray, t_min, t_max, rec, media, org, 0u, nullptr);
+    } else {
+      return traverse_wide<R, C>(sv, ray, t_min, t_max, rec, media, org, tally);
+    }
   } else {
     if constexpr (sizeof(R) == sizeof(float)) return traverse_lane_deferred<C>(sv, root, ray, t_min, t_max, rec, media, org, tally);
     else return traverse_lane<R, C, 0>(sv, root, ray, t_min, t_max, rec, media, org, 0u, tally);

@@ -129,6 +129,10 @@ struct FrameParams {
   // u % n_pixels).  `n_samples` = samples of this launch.  Frames whose paths are short and all bright (a textured globe in
   // front of a sky) otherwise spend two thirds of their time in the radiance atomics.
   uint32_t chunk, n_samples;
+  // F_EXACT kernels: (pixel, sample) of the paths that met a tie (see traverse_wide) and were given up, to be traced again by
+  // k_redo_paths; `redo_cap` entries of two words, the number of entries asked for in word 1 of the ray counter block.
+  uint32_t* redo_list;
+  uint32_t redo_cap;
 };
 
 struct Segment {
@@ -532,6 +536,10 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
   Rec<R> rec;
   LaneBoxTest<R> box(Ray<R>{});
   // the test of one leaf against the lane's ray
+  // F_EXACT: two different leaves at exactly the same distance - the order of the tests would decide (see traverse_wide)
+  constexpr bool EXACT = WIDE && C::has(F_EXACT) && sizeof(R) == sizeof(double);
+  bool tie = false;
+  unsigned long long redone_rays = 0;  // per lane: rays of the paths this lane gave up
   auto step_leaf = [&](uint32_t word, Stream& media) {
     if constexpr (DEFER) {
       RayInv<R> ri(st.ray.d);
@@ -539,10 +547,17 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
       R t;
       int side;
       if (leaf_t<R, C>(sv, word, st.ray, ri, (R)0.001, closest, media, st.org, t, side, visit_bit(word, 0))) {
-        closest = t; best_leaf = (int)(word & LEAF_INDEX_MASK); best_side = side;
+        const int leaf = (int)(word & LEAF_INDEX_MASK);
+        if constexpr (EXACT) tie = tie | (best_leaf >= 0 && best_leaf != leaf && t == closest);
+        closest = t; best_leaf = leaf; best_side = side;
       }
     } else {
-      if (leaf_hit<R, C, 0>(sv, word, st.ray, (R)0.001, closest, rec, media, st.org)) { closest = rec.t; any = true; }
+      const int prev_leaf = rec.leaf;
+      const R prev_t = closest;
+      if (leaf_hit<R, C, 0>(sv, word, st.ray, (R)0.001, closest, rec, media, st.org)) {
+        if constexpr (EXACT) tie = tie | (any && rec.leaf >= 0 && prev_leaf >= 0 && prev_leaf != rec.leaf && rec.t == prev_t);
+        closest = rec.t; any = true;
+      }
     }
   };
   RT_STAMP_INIT();  // diagnostic build: cycles of [0] restart blocks, [1] box steps, [2] leaf steps; lanes taking part in [3] box steps,
@@ -551,6 +566,23 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
     const unsigned long long idle = __ballot(i < 0);
     if ((uint32_t)__popcll(idle) >= (WIDE ? kRestartLanesWide : kRestartLanes) || idle == ~0ull) {
       bool to_scatter = false;
+      if constexpr (EXACT) {
+        // A walk that met a tie: the path is given up here - nothing of it has reached the sums yet (only a path's last vertex
+        // adds radiance) - and goes on the list of paths that k_redo_paths traces again with the list walk.  Its rays so far
+        // leave the count; the second tracing counts them.  A full list leaves the path with what the walk reported.
+        if (i < 0 && active && tie) {
+          const uint32_t slot = atomicAdd(reinterpret_cast<uint32_t*>(ray_count + 1), 1u);
+          if (slot < fp.redo_cap) {
+            fp.redo_list[2u * slot] = st.pixel;
+            fp.redo_list[2u * slot + 1u] = st.sample;
+            redone_rays += (unsigned long long)(bounce + 1u);
+            active = false;
+            best_leaf = -1;
+            resume = 0u;
+          }
+        }
+        if (i < 0) tie = false;
+      }
       if constexpr (DEFER) {
         if (i < 0 && active && best_leaf >= 0) {  // the walk has ended on a hit: its record, once
           finalize_hit<R, C>(sv, st.ray, closest, best_leaf, best_side, rec);
@@ -671,6 +703,9 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
   }
   RT_STAMP_FLUSH(ray_count);
   if (lane == 0u && n_rays != 0ull) atomicAdd(ray_count, n_rays);
+  if constexpr (EXACT) {
+    if (redone_rays != 0ull) atomicAdd(ray_count, 0ull - redone_rays);  // modulo 2^64: a subtraction
+  }
 }
 
 // ---- material-sorted pipeline: trace kernel + shade kernel ----
@@ -911,6 +946,42 @@ __global__ __launch_bounds__(256) void k_sample_radiance(DeviceScene<R> sc, uint
     out[(size_t)i * 4u + 1] = (double)sum.y;
     out[(size_t)i * 4u + 2] = (double)sum.z;
     out[(size_t)i * 4u + 3] = (double)n_rays;
+  }
+}
+
+// F_EXACT: the paths k_paths_stepwise gave up at a tie (FrameParams::redo_list), traced again from their primary ray with the list
+// walk, which keeps the reference's order of tests (src/bvh.rs:108-119) and with it the reference's answer among surfaces at
+// exactly the same distance.  A handful of paths per frame at most: one thread each.
+template <class R, class C>
+__global__ __launch_bounds__(256) void k_redo_paths(DeviceScene<R> sc, FrameParams fp, uint32_t n, unsigned long long* ray_count, R* accum) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const SceneView<R, C> sv = make_view<R, C>(sc, lds);
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t px = fp.redo_list[2u * i], sm = fp.redo_list[2u * i + 1u];
+    Ray<R> ray = primary_ray<R, C::relaxed()>(sc.camera, fp.width, fp.height, px, sm, fp.seed);
+    V3<R> thr((R)1, (R)1, (R)1);
+    unsigned long long n_rays = 0;
+    Origin org;
+    for (uint32_t bounce = 0; bounce < fp.max_depth; ++bounce) {
+      ++n_rays;
+      Stream media(fp.seed, px, sm, bounce, STAGE_MEDIA);
+      Rec<R> rec;
+      if (!traverse_lane<R, C, 0>(sv, sc.root_link, ray, (R)0.001, Lim<R>::inf(), rec, media, org, 0u, nullptr)) {
+        add_radiance(accum, px, thr * background_color<R, C>(sc.background, ray.d));
+        break;
+      }
+      Stream rng(fp.seed, px, sm, bounce, STAGE_SCATTER);
+      V3<R> emitted, attenuation;
+      Ray<R> scattered;
+      const bool alive = shade_hit<R, C>(sv, ray, rec, rng, emitted, attenuation, scattered);
+      add_radiance(accum, px, thr * emitted);
+      if (!alive) break;
+      thr = thr * attenuation;
+      ray = scattered;
+      org = Origin(rec.leaf, rec.side);
+    }
+    atomicAdd(ray_count, n_rays);
   }
 }
 

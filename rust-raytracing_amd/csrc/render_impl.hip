@@ -18,6 +18,12 @@ template <class R> KernelTable<R> table_for(int preset) {
     case PRESET_FLATALL_TOP: return kernel_table<R, PRESET_FLATALL_TOP>();
     case PRESET_BALLS_WIDE: return kernel_table<R, PRESET_BALLS_WIDE>();
     case PRESET_FLATALL_WIDE: return kernel_table<R, PRESET_FLATALL_WIDE>();
+    case PRESET_BALLS_WIDE_EXACT:  // double precision only: a single-precision image never asks for them
+      if constexpr (sizeof(R) == 8) return kernel_table<R, PRESET_BALLS_WIDE_EXACT>();
+      else return kernel_table<R, PRESET_BALLS_WIDE>();
+    case PRESET_FLATALL_WIDE_EXACT:
+      if constexpr (sizeof(R) == 8) return kernel_table<R, PRESET_FLATALL_WIDE_EXACT>();
+      else return kernel_table<R, PRESET_FLATALL_WIDE>();
     default: break;
   }
   return kernel_table<R, PRESET_ALL_TOP>();
@@ -65,7 +71,7 @@ template <class R> void layout_sections(BlobLayout& lay) {
 
 template <class R>
 int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink>& links, int root_link, const std::vector<int>& sub_root_of_object,
-                int preset, SceneImage<R>& im, const std::vector<WideTmp>* wide, const std::vector<uint32_t>* pre) {
+                int preset, SceneImage<R>& im, const std::vector<WideTmp>* wide, const std::vector<uint32_t>* pre, bool exact) {
   BlobLayout lay{};
   lay.n_links = (uint32_t)links.size();
   lay.n_objects = (uint32_t)s.n_objects;
@@ -114,7 +120,9 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
   // is walked from LDS and is the faster of the two).  RTAMD_WIDE_ALWAYS=1: wherever a wide tree exists (measurement switch).
   if (wide && !wide->empty() && (preset == PRESET_BALLS_LDS || preset == PRESET_FLATALL_LDS) &&
       (lay.total_bytes > kLdsAllMax || getenv("RTAMD_WIDE_ALWAYS"))) {
-    preset = preset == PRESET_BALLS_LDS ? PRESET_BALLS_WIDE : PRESET_FLATALL_WIDE;
+    // `exact`: the four-wide tree stands in for the list in `links` (the caller's tree): the kernels with the reference's leaf
+    // arithmetic and tie rule (F_EXACT)
+    preset = preset == PRESET_BALLS_LDS ? (exact ? PRESET_BALLS_WIDE_EXACT : PRESET_BALLS_WIDE) : (exact ? PRESET_FLATALL_WIDE_EXACT : PRESET_FLATALL_WIDE);
     lay.n_wide = (uint32_t)wide->size();
     layout_sections<R>(lay);
   }
@@ -132,6 +140,10 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
       std::memset(&n, 0, sizeof(n));
       for (int ch = 0; ch < 4; ++ch) {
         n.child[ch] = used[ch] ? w.child[ch] : kWideNone;
+        // "plain shape, no wrapper" is a property of this image's objects (the tree may have been built over another image's, in
+        // which a sphere under wrappers was re-centred and became plain)
+        if (used[ch] && (w.child[ch] & LEAF_FLAG))
+          n.child[ch] = (w.child[ch] & ~LEAF_SIMPLE) | ((s.objects[w.child[ch] & LEAF_INDEX_MASK].flags & 15u) == 0u ? LEAF_SIMPLE : 0u);
         for (int k = 0; k < 3; ++k) {
           n.lo[k][ch] = used[ch] ? round_down<float>(w.lo[ch][k]) : inf;
           n.hi[k][ch] = used[ch] ? round_up<float>(w.hi[ch][k]) : inf;
@@ -272,7 +284,9 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
     for (uint32_t word : *pre) {
       if (d.n_pre >= kWidePre) return fail(RT_E_INVALID, "internal error: too many leaves kept outside the four-wide tree");
       // see the links above: a re-centred sphere's front_face rule is read from the object's flags
-      d.pre[d.n_pre++] = (!single && (s.objects[word & LEAF_INDEX_MASK].flags & OBJ_FRONT_CHAIN)) ? (word & ~LEAF_SIMPLE) : word;
+      const uint32_t of = s.objects[word & LEAF_INDEX_MASK].flags;
+      const uint32_t w = (word & ~LEAF_SIMPLE) | ((of & 15u) == 0u ? LEAF_SIMPLE : 0u);
+      d.pre[d.n_pre++] = (!single && (of & OBJ_FRONT_CHAIN)) ? (w & ~LEAF_SIMPLE) : w;
     }
   uint32_t top_bytes = kLdsTopMax;
   if (const char* e = getenv("RTAMD_TOP_LDS_BYTES")) top_bytes = (uint32_t)std::max(0, atoi(e));  // measurement switch
@@ -337,6 +351,8 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
     if (const char* e = getenv("RTAMD_CHUNK")) chunk = im.preset == PRESET_SPHERES ? (uint32_t)std::max(1, atoi(e)) : 1u;  // measurement switch
     fp.chunk = chunk;
     fp.n_samples = n_samples;
+    fp.redo_list = c->d_redo;
+    fp.redo_cap = kRedoCapacity;
     const unsigned long long total_paths = (unsigned long long)n_pixels * ((n_samples + chunk - 1) / chunk);  // units the path cursor counts
 #ifdef RT_STAMPS
     if (counters_override) return fail(RT_E_UNSUPPORTED, "the diagnostic build has no allocation-free entry point");
@@ -362,11 +378,22 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
       variant = im.table.paths_persistent(grid, im.lds_bytes, c->stream, im.dev, fp, total_paths, cnt + 8, cnt, accum);
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     HIP_TRY(hipGetLastError());
-    unsigned long long rays_stack = 0;
-    unsigned long long* const rays_dst = host_rays ? host_rays : &rays_stack;
-    HIP_TRY(hipMemcpyAsync(rays_dst, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    unsigned long long rays_stack[2] = {0, 0};
+    unsigned long long* const rays_dst = host_rays ? host_rays : rays_stack;  // word 0 rays, word 1 paths given up at a tie
+    HIP_TRY(hipMemcpyAsync(rays_dst, cnt, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    const unsigned long long rays = *rays_dst;
+    uint64_t redone = 0;
+    if (rays_dst[1] != 0ull) {
+      // Paths on which two different surfaces lay at exactly the same distance (a handful, if any): traced again by the list walk in
+      // the reference's order.  Requests beyond the list's capacity stayed with what the four-wide walk reported.
+      redone = std::min<uint64_t>(rays_dst[1], kRedoCapacity);
+      const uint32_t redo_grid = (uint32_t)std::min<uint64_t>((redone + kBlock - 1) / kBlock, (uint64_t)c->n_cus * 4u);
+      im.table.redo_paths(redo_grid, im.lds_bytes, c->stream, im.dev, fp, (uint32_t)redone, cnt, accum);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(rays_dst, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    const unsigned long long rays = rays_dst[0];
 #ifdef RT_STAMPS
     {
       std::vector<unsigned long long> all(kRayCountWords);
@@ -399,6 +426,7 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
       stats->lds_bytes = im.lds_bytes;
       stats->scene_in_lds = (uint32_t)im.preset;
       stats->kernel_variant = variant;
+      stats->paths_redone = redone;
     }
     return RT_OK;
   }
@@ -592,7 +620,7 @@ template <class R> int resolve_impl(rt_context* c, const void* accum_dev, size_t
 #define RTI_INSTANTIATE(R)                                                                                                                   \
   template void layout_sections<R>(BlobLayout&);                                                                                        \
   template int build_image<R>(rt_context*, const rt_scene_desc&, const std::vector<TmpLink>&, int, const std::vector<int>&, int, SceneImage<R>&, \
-                              const std::vector<WideTmp>*, const std::vector<uint32_t>*);                                                \
+                              const std::vector<WideTmp>*, const std::vector<uint32_t>*, bool);                                                \
   template int render_accum_impl<R>(rt_context*, const rt_render_params&, void*, rt_stats*, unsigned long long*, unsigned long long*);                                              \
   template int trace_batch_impl<R>(rt_context*, const rt_ray*, size_t, rt_hit*, uint64_t, int);                                                   \
   template int pairs_kernel_impl<R>(rt_context*, int, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint32_t*, size_t, uint64_t, void*, \

@@ -271,6 +271,7 @@ int rt_create(rt_context** out, int device) {
     if (hipEventCreate(&ev) != hipSuccess) return cleanup(RT_E_HIP, "hipEventCreate failed");
   if (hipMalloc((void**)&c->d_counters, sizeof(uint32_t) * kCounterWords) != hipSuccess) return cleanup(RT_E_HIP, "hipMalloc counters failed");
   if (hipMalloc((void**)&c->d_ray_count, sizeof(unsigned long long) * rti::kRayCountWords) != hipSuccess) return cleanup(RT_E_HIP, "hipMalloc ray counter failed");
+  if (hipMalloc((void**)&c->d_redo, sizeof(uint32_t) * 2u * rti::kRedoCapacity) != hipSuccess) return cleanup(RT_E_HIP, "hipMalloc redo list failed");
   if (hipHostMalloc((void**)&c->h_rays, 64, hipHostMallocDefault) != hipSuccess) return cleanup(RT_E_HIP, "hipHostMalloc failed");
   // set-up of the allocation-free entry point: this device's address of the static scratch array, looked up with the device current
   if (int rc = scratch_for_device(device, &c->scratch)) { std::string m = g_err; return cleanup(rc, m); }
@@ -289,6 +290,7 @@ void rt_destroy(rt_context* c) {
   if (c->d_rgb) (void)hipFree(c->d_rgb);
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->d_ray_count) (void)hipFree(c->d_ray_count);
+  if (c->d_redo) (void)hipFree(c->d_redo);
   if (c->h_rays) (void)hipHostFree(c->h_rays);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -531,47 +533,34 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   std::vector<int> sub_root64((size_t)s->n_objects, LINK_END);
   int preset64 = preset;
   const bool relinked = spliced_any || skipped_any;
-  // Scenes of spheres only: the caller's tree in its four-wide form as well (see wide_from_links), which the double-precision
-  // image takes when it does not fit in LDS.  RTAMD_NO_WIDE=1 / RTAMD_F64_LIST=1 keep the list.
-  std::vector<WideTmp> wide64;
-  std::vector<uint32_t> pre64;  // leaves kept outside that tree, tested ahead of the walk
-  const bool want_wide64 = preset == PRESET_BALLS_LDS && !std::getenv("RTAMD_NO_WIDE") && !std::getenv("RTAMD_F64_LIST");
-  auto fold64 = [&](const std::vector<TmpLink>& list, int list_root) {
-    if (!want_wide64) return;
-    // Two objects with the same geometry that are not copies of one another (different materials) would tie on every ray that hits
-    // them, and then the order of the tests does decide: such a scene keeps the list.  (64-bit hashes of tag and parameters; a chance
-    // collision only costs the faster walk.)
-    {
-      std::vector<uint64_t> keys;
-      keys.reserve(list.size() / 2 + 1);
-      for (const TmpLink& l : list) {
-        if (!(l.hit & LEAF_FLAG)) continue;
-        const rt_shape& sh = s->shapes[s->objects[l.hit & LEAF_INDEX_MASK].geom];
-        uint64_t h = 0xCBF29CE484222325ull ^ (uint64_t)(uint32_t)sh.tag;
-        for (int k = 0; k < 9; ++k) {
-          uint64_t b;
-          std::memcpy(&b, &sh.p[k], 8);
-          h = (h ^ b) * 0x100000001B3ull;
-          h ^= h >> 29;
-        }
-        keys.push_back(h);
-      }
-      std::sort(keys.begin(), keys.end());
-      if (std::adjacent_find(keys.begin(), keys.end()) != keys.end()) {
-        if (timing) std::fprintf(stderr, "rt_upload_scene: caller's tree keeps the list walk (coincident objects)\n");
-        return;
-      }
+  // Two different objects with the same geometry (same wrappers, same shape; different materials, or they would be copies of one
+  // another and all but one left out above) tie on every ray that hits them, and the reference decides such ties by the order of its
+  // walk: a scene that holds such a pair keeps the list walk of the caller's tree in double precision.  A medium never ties (its
+  // distance is drawn).  64-bit hashes; a chance collision only costs the faster walk.
+  bool coincident = false;
+  if (!uniform) {
+    std::vector<uint64_t> keys;
+    keys.reserve((size_t)s->n_objects);
+    for (int i = 0; i < s->n_objects; ++i) {
+      const rt_object& o = objects64[(size_t)i];
+      if ((o.flags & (RT_OBJ_SUB_BVH | RT_OBJ_MEDIUM)) || skip[(size_t)i]) continue;
+      const rt_shape& sh = s->shapes[o.geom];
+      uint64_t h = 0xCBF29CE484222325ull ^ (uint64_t)(uint32_t)sh.tag ^ ((uint64_t)o.flags << 8);
+      auto mix = [&](double v) {
+        uint64_t b;
+        std::memcpy(&b, &v, 8);
+        h = (h ^ b) * 0x100000001B3ull;
+        h ^= h >> 29;
+      };
+      for (int k = 0; k < 9; ++k) mix(sh.p[k]);
+      if (o.flags & RT_OBJ_TRANSLATE) for (int k = 0; k < 3; ++k) mix(o.offset[k]);
+      if (o.flags & RT_OBJ_ROTATE_Y) { mix(o.sin_theta); mix(o.cos_theta); }
+      keys.push_back(h);
     }
-    const FastTreeBuilder shapes_of(*s);  // sphere scenes have no nested trees: the caller's objects as they are
-    const int need = wide_from_links(list, list_root, wide64, &shapes_of, &pre64);
-    if (need > (int)kWideStack) { wide64.clear(); pre64.clear(); }
-    if (timing) std::fprintf(stderr, "rt_upload_scene: caller's tree four-wide: %zu nodes, stack need %d (limit %u)\n", wide64.size(), need, kWideStack);
-  };
-  // the folding reads its list only and runs on a thread of its own while this one goes on to the library's own tree
-  std::vector<TmpLink> fold_list;
-  std::thread t_fold;
-  struct JoinOnExit { std::thread& t; ~JoinOnExit() { if (t.joinable()) t.join(); } } fold_guard{t_fold};
-  if (!relinked && want_wide64) t_fold = std::thread([&, root] { fold64(lb.links, root); });
+    std::sort(keys.begin(), keys.end());
+    coincident = std::adjacent_find(keys.begin(), keys.end()) != keys.end();
+    if (coincident && timing) std::fprintf(stderr, "rt_upload_scene: double precision keeps the list walk of the caller's tree (coincident objects)\n");
+  }
   if (relinked) {
     LinkBuilder lbs(scene64);
     lbs.splice = &splice;
@@ -581,12 +570,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     for (int i = 0; i < s->n_objects && lbs.err.empty(); ++i)
       if ((s->objects[i].flags & RT_OBJ_SUB_BVH) && !splice[(size_t)i]) sub_root64[(size_t)i] = lbs.node(s->objects[i].geom, LINK_END, 0, tree64++);
     if (!lbs.err.empty()) return fail(RT_E_INVALID, "rt_upload_scene: " + lbs.err);
-    const int root_before = root64;
     links64 = reorder(lbs.links, root64, sub_root64);
-    if (want_wide64) {
-      fold_list.swap(lbs.links);
-      t_fold = std::thread([&, root_before] { fold64(fold_list, root_before); });
-    }
     if (has_nested && !nested_left64 && preset == PRESET_ALL_LDS) preset64 = PRESET_FLATALL_LDS;
     mark("f64 list: nested trees spliced, copies left out");
   }
@@ -625,27 +609,36 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     HIP_TRY(hipMalloc((void**)&c->d_images, sizeof(DImage) * host_images.size()));
     HIP_TRY(hipMemcpy(c->d_images, host_images.data(), sizeof(DImage) * host_images.size(), hipMemcpyHostToDevice));
   }
-  // the three images are independent of one another: the double-precision ones are built on threads of their own
-  const bool want_own64 = own_tree && !std::getenv("RTAMD_NO_F64_OWN_TREE");
+  // Double precision, default image.  The closest hit does not depend on the tree that is walked, only on the leaf tests, unless two
+  // different surfaces lie at exactly the same distance; so where the library has a four-wide tree of its own (every nested tree
+  // dissolved, the walk's stack fits) the double-precision kernels walk that one as well, with the reference's leaf arithmetic on the
+  // caller's objects (spliced nested trees keep their holders' wrappers: the same operations bit for bit), flag the rays on which
+  // two leaves tie and have those traced by the list walk of the caller's tree, which the image carries too (F_EXACT, kernels.h).
+  // Kept on the list walk: scenes in which a texture reads a leftover (u, v) (the leftover depends on the order of the tests),
+  // scenes with coincident objects (every ray on them would tie), and RTAMD_F64_LIST=1.
+  const bool exact_own = own_tree && !wide_nodes.empty() && !stale_uv_read && !coincident && !nested_left64 && !std::getenv("RTAMD_F64_LIST");
+  // RT_F64_OWN_TREE: the library's tree in double with its own cheaper leaf forms (boxes as slabs, re-centred spheres), compared with
+  // the reference by tolerance; for sphere scenes that is the default image itself
+  const bool want_own64 = own_tree && preset32 != PRESET_BALLS_LDS && !std::getenv("RTAMD_NO_F64_OWN_TREE");
   int rc_sd = RT_OK, rc_own = RT_OK;
   std::string err_sd, err_own;
   const int device = c->device;
-  if (t_fold.joinable()) t_fold.join();
   std::thread t_sd([&] {
     if (hipSetDevice(device) != hipSuccess) { rc_sd = RT_E_HIP; err_sd = "hipSetDevice failed"; return; }
-    rc_sd = relinked ? build_image<double>(c, scene64, links64, root64, sub_root64, preset64, c->sd, &wide64, &pre64)
-                        : build_image<double>(c, *s, links, root, sub_root, preset, c->sd, &wide64, &pre64);
+    const std::vector<WideTmp>* w = exact_own ? &wide_nodes : nullptr;
+    const std::vector<uint32_t>* p = exact_own ? &wide_pre : nullptr;
+    rc_sd = relinked ? build_image<double>(c, scene64, links64, root64, sub_root64, preset64, c->sd, w, p, exact_own)
+                     : build_image<double>(c, *s, links, root, sub_root, preset, c->sd, w, p, exact_own);
     if (rc_sd != RT_OK) err_sd = g_err;
   });
-  // RT_F64_OWN_TREE: the library's tree once more, in double
   std::thread t_own([&] {
     if (!want_own64) return;
     if (hipSetDevice(device) != hipSuccess) { rc_own = RT_E_HIP; err_own = "hipSetDevice failed"; return; }
-    rc_own = build_image<double>(c, scene32, fast_links, fast_root, fast_sub_root, preset32, c->sd_own, &wide_nodes, &wide_pre);
+    rc_own = build_image<double>(c, scene32, fast_links, fast_root, fast_sub_root, preset32, c->sd_own, &wide_nodes, &wide_pre, false);
     if (rc_own != RT_OK) err_own = g_err;
   });
-  rc = own_tree ? build_image<float>(c, scene32, fast_links, fast_root, fast_sub_root, preset32, c->sf, &wide_nodes, &wide_pre)
-                : build_image<float>(c, *s, links, root, sub_root, preset, c->sf, nullptr, nullptr);
+  rc = own_tree ? build_image<float>(c, scene32, fast_links, fast_root, fast_sub_root, preset32, c->sf, &wide_nodes, &wide_pre, false)
+                : build_image<float>(c, *s, links, root, sub_root, preset, c->sf, nullptr, nullptr, false);
   t_sd.join();
   t_own.join();
   if (rc == RT_OK && rc_sd != RT_OK) rc = fail(rc_sd, err_sd);

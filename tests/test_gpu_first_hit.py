@@ -306,12 +306,12 @@ def test_wide_walk_and_list_walk_agree(gpu, rtamd, oracle, earth_rgb, name, kw, 
 
 
 @pytest.mark.parametrize("name,kw", [("random", {}), ("mega-spheres", {"mega_grid": 60, "width": 160, "spp": 4})])
-def test_f64_wide_walk_of_the_callers_tree_is_exact(gpu, rtamd, oracle, earth_rgb, name, kw, monkeypatch):
-    """Scenes of spheres only: the default double-precision image walks the caller's tree - the reference's nodes, boxes and leaves,
-    exact copies left out - folded four boxes to a node, nearest child first, instead of as a list in the reference's order.  No two
-    different spheres lie at the same distance along a ray, so the order of the tests decides nothing: ids, t, p and the normal of
-    100 000 rays and a small frame's ray count and sums must equal the list walk's (RTAMD_F64_LIST) bit for bit - the other tests
-    hold this same image to the oracle."""
+def test_f64_walk_of_the_librarys_tree_is_exact(gpu, rtamd, oracle, earth_rgb, name, kw, monkeypatch):
+    """The default double-precision image of a scene too large for LDS walks the library's own four-wide tree, nearest child first,
+    with the reference's leaf arithmetic; the closest hit does not depend on the tree, and a ray on which two different leaves tie
+    is traced again by the list walk of the caller's tree.  So ids, t, p and the normal of 100 000 rays and a small frame's ray
+    count and sums must equal the list walk's (RTAMD_F64_LIST: the caller's tree in the reference's order) bit for bit - the
+    other tests hold this same image to the oracle."""
     hs, _ = make_pair(rtamd, oracle, name, earth=earth_rgb, **kw)
     rng = np.random.default_rng(8642)
     lo, hi = SCENE_BOXES.get(name, ((-60, 0.05, -60), (60, 3, 60)))
@@ -327,7 +327,7 @@ def test_f64_wide_walk_of_the_callers_tree_is_exact(gpu, rtamd, oracle, earth_rg
     _, fb, sb = gpu.render(0, 2, precision=rtamd.F64, seed=3)
     monkeypatch.delenv("RTAMD_F64_LIST")
     gpu.upload(hs)
-    assert sa["scene_in_lds"] == 9 and sb["scene_in_lds"] in (5, 6), (sa["scene_in_lds"], sb["scene_in_lds"])
+    assert sa["scene_in_lds"] == 11 and sb["scene_in_lds"] in (5, 6), (sa["scene_in_lds"], sb["scene_in_lds"])
     for f in ID_FIELDS + ("t", "p", "n"):
         assert np.array_equal(a[f], b[f]), (name, f)
     assert a0.tobytes() == b0.tobytes()  # the plain query walks the list in either image (leftover (u, v) included)
@@ -337,12 +337,12 @@ def test_f64_wide_walk_of_the_callers_tree_is_exact(gpu, rtamd, oracle, earth_rg
 
 def test_coincident_spheres_keep_the_list_walk(gpu, rtamd, oracle, earth_rgb):
     """Two spheres with the same centre and radius but different materials tie on every ray that hits them, and which one the
-    reference reports hangs on the order of its walk: a sphere scene that holds such a pair must keep the list walk of the caller's
-    tree in double precision (preset 5 / 6 instead of the four-wide 9)."""
+    reference reports hangs on the order of its walk: a scene that holds such a pair must keep the list walk of the caller's
+    tree in double precision (preset 5 / 6 instead of the four-wide 11)."""
     from custom_scene import EditedScene
     hs, _ = make_pair(rtamd, oracle, "random", earth=earth_rgb)
     gpu.upload(hs)
-    assert gpu.render_accum(None, 0, 1, precision=rtamd.F64, seed=3)["scene_in_lds"] == 9
+    assert gpu.render_accum(None, 0, 1, precision=rtamd.F64, seed=3)["scene_in_lds"] == 11
     ed = EditedScene(rtamd, hs)
     spheres = np.nonzero(ed.shapes["tag"] == 0)[0]
     a, b = next((int(x), int(y)) for x in spheres for y in spheres if x < y and ed.shapes["material"][x] != ed.shapes["material"][y])
@@ -390,8 +390,8 @@ def test_f64_on_the_librarys_own_tree(gpu, rtamd, oracle, earth_rgb, name, mega_
         return
     va = gpu.trace_batch(rays[:20000], precision=rtamd.F64, seed=99, visits=True)
     vb = gpu.trace_batch(rays[:20000], precision=rtamd.F64_OWN_TREE, seed=99, visits=True)
-    print("%s: box tests per ray %.1f on the reference's tree, %.1f on the library's" % (name, va["u"].mean(), vb["u"].mean()))
-    assert vb["u"].mean() < va["u"].mean()
+    print("%s: box tests per ray %.1f by default, %.1f with RT_F64_OWN_TREE" % (name, va["u"].mean(), vb["u"].mean()))
+    assert vb["u"].mean() <= va["u"].mean()  # the default walks the library's tree as well
 
 
 @pytest.mark.parametrize("name,switch", [("random", "RTAMD_KEEP_COPIES"), ("final-scene", "RTAMD_KEEP_NESTED")])
@@ -413,7 +413,7 @@ def test_f64_list_variants_agree(gpu, rtamd, oracle, earth_rgb, name, switch, mo
     for f in ID_FIELDS + ("t", "p", "n"):
         assert np.array_equal(a[f], b[f]), (name, switch, f)
     sa = gpu.render_accum(None, 0, 1, precision=rtamd.F64, seed=3)
-    assert sa["scene_in_lds"] in (5, 6, 7, 8, 9), sa["scene_in_lds"]  # by default neither scene takes a nested-tree preset
+    assert sa["scene_in_lds"] in (5, 6, 7, 8, 11, 12), sa["scene_in_lds"]  # by default neither scene takes a nested-tree preset
 
 
 

@@ -272,7 +272,7 @@ def test_records_built_after_the_walk_render_the_same_frame(gpu, rtamd, oracle, 
     hs, _ = make_pair(rtamd, oracle, "final-scene", earth=earth_rgb, width=96, aspect=1.0, spp=4)
     gpu.upload(hs)
     _, a, sa = gpu.render(0, 4, precision=rtamd.F64, seed=31)
-    assert sa["scene_in_lds"] in (7, 8)  # a stepwise preset: nested trees spliced into the world's tree
+    assert sa["scene_in_lds"] in (7, 8, 12)  # a stepwise preset: nested trees spliced into the world's tree (12: the library's four-wide tree)
     monkeypatch.setenv("RTAMD_EAGER_RECORDS", "1")
     gpu.upload(hs)
     _, b, sb = gpu.render(0, 4, precision=rtamd.F64, seed=31)
@@ -346,7 +346,7 @@ def test_million_sphere_field(gpu, rtamd):
     assert np.quantile(t_rel, 0.999) < 1e-5
     _, a64, s64 = gpu.render(0, 4, precision=rtamd.F64, seed=13)
     _, a32, s32 = gpu.render(0, 4, precision=rtamd.F32, seed=13)
-    assert s64["camera_rays"] == hs.width * hs.height * 4 and s64["scene_in_lds"] in (4, 6, 9) and s32["scene_in_lds"] in (4, 6, 8, 9, 10)  # 9, 10: the four-wide walk of the own tree
+    assert s64["camera_rays"] == hs.width * hs.height * 4 and s64["scene_in_lds"] in (4, 6, 9, 11) and s32["scene_in_lds"] in (4, 6, 8, 9, 10)  # 9, 10: the four-wide walk of the own tree
     assert abs(int(s32["rays"]) - int(s64["rays"])) <= 5e-3 * s64["rays"], (s32["rays"], s64["rays"])
     m32, m64 = np.clip(a32 / 4, 0, 1).reshape(-1, 3).mean(0), np.clip(a64 / 4, 0, 1).reshape(-1, 3).mean(0)
     assert (np.abs(m32 - m64) / m64).max() < 1e-2, (m32, m64)
