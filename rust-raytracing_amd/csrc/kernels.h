@@ -472,6 +472,9 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? (sizeof(R) == 8 ? RT_NESTED
 #ifndef RT_STEP_WAVES_FULL_F64
 #define RT_STEP_WAVES_FULL_F64 3  // double precision: final-scene on the library's tree 3.71 / 3.95 / 3.83 Grays/s at 4 / 3 / 2 waves per SIMD, on the caller's tree no difference
 #endif
+#ifndef RT_STEP_WAVES_EXACT_F64
+#define RT_STEP_WAVES_EXACT_F64 2  // the reference's leaf arithmetic on the four-wide walk (six rectangles to a box, wrapped spheres): all 256 registers and no spills, final-scene 4.05 -> 4.2 Grays/s against three waves
+#endif
 #ifndef RT_WIDE_WAVES_F32
 #define RT_WIDE_WAVES_F32 0  // != 0: waves per SIMD asked for the single-precision four-wide kernels (measurement switch; needs RT_WIDE_STACK to match the LDS)
 #endif
@@ -506,7 +509,7 @@ constexpr int kTurnsPerCheck = RT_TURNS;
 constexpr int kWideStepsPerTurn = RT_WIDE_STEPS;  // node steps of the four-wide walk between two looks at the waiting leaves
 
 template <class R, class C, bool FIXED_GRAB, bool DEFER_LIST = false>
-__global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == WALK_LANE_WIDE && sizeof(R) == 4) ? RT_WIDE_WAVES_F32 : C::has(F_NESTED) ? RT_NESTED_WAVES : (C::has(F_NOISE) ? (sizeof(R) == 8 ? RT_STEP_WAVES_FULL_F64 : RT_STEP_WAVES_FULL) : RT_STEP_WAVES)) void k_paths_stepwise(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
+__global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == WALK_LANE_WIDE && sizeof(R) == 4) ? RT_WIDE_WAVES_F32 : C::has(F_NESTED) ? RT_NESTED_WAVES : (C::has(F_NOISE) ? (sizeof(R) == 8 ? (C::has(F_EXACT) ? RT_STEP_WAVES_EXACT_F64 : RT_STEP_WAVES_FULL_F64) : RT_STEP_WAVES_FULL) : RT_STEP_WAVES)) void k_paths_stepwise(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
                                                         unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
   extern __shared__ __align__(16) uint8_t lds[];
   const SceneView<R, C> sv = make_view<R, C>(sc, lds);
@@ -949,9 +952,10 @@ __global__ __launch_bounds__(256) void k_sample_radiance(DeviceScene<R> sc, uint
   }
 }
 
-// F_EXACT: the paths k_paths_stepwise gave up at a tie (FrameParams::redo_list), traced again from their primary ray with the list
-// walk, which keeps the reference's order of tests (src/bvh.rs:108-119) and with it the reference's answer among surfaces at
-// exactly the same distance.  A handful of paths per frame at most: one thread each.
+// F_EXACT: the paths k_paths_stepwise gave up at a tie (FrameParams::redo_list), traced again from their primary ray, one thread
+// each: every ray by the four-wide walk and, where that meets the tie, by the list walk, which keeps the reference's order of tests
+// (src/bvh.rs:108-119) and with it the reference's answer among surfaces at exactly the same distance (closest_hit).  A few
+// hundred paths per frame at most.
 template <class R, class C>
 __global__ __launch_bounds__(256) void k_redo_paths(DeviceScene<R> sc, FrameParams fp, uint32_t n, unsigned long long* ray_count, R* accum) {
   extern __shared__ __align__(16) uint8_t lds[];
@@ -967,7 +971,7 @@ __global__ __launch_bounds__(256) void k_redo_paths(DeviceScene<R> sc, FramePara
       ++n_rays;
       Stream media(fp.seed, px, sm, bounce, STAGE_MEDIA);
       Rec<R> rec;
-      if (!traverse_lane<R, C, 0>(sv, sc.root_link, ray, (R)0.001, Lim<R>::inf(), rec, media, org, 0u, nullptr)) {
+      if (!closest_hit<R, C>(sv, sc.root_link, ray, (R)0.001, Lim<R>::inf(), rec, media, org)) {
         add_radiance(accum, px, thr * background_color<R, C>(sc.background, ray.d));
         break;
       }

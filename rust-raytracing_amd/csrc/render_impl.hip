@@ -387,6 +387,11 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
       // Paths on which two different surfaces lay at exactly the same distance (a handful, if any): traced again by the list walk in
       // the reference's order.  Requests beyond the list's capacity stayed with what the four-wide walk reported.
       redone = std::min<uint64_t>(rays_dst[1], kRedoCapacity);
+      if (const char* e = getenv("RTAMD_DUMP_REDO")) {  // diagnostic: the first (pixel, sample) pairs of the list, on stderr
+        std::vector<uint32_t> head(2 * std::min<uint64_t>(redone, (uint64_t)std::max(1, atoi(e))));
+        HIP_TRY(hipMemcpy(head.data(), c->d_redo, head.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k + 1 < head.size(); k += 2) fprintf(stderr, "redo %u %u\n", head[k], head[k + 1]);
+      }
       const uint32_t redo_grid = (uint32_t)std::min<uint64_t>((redone + kBlock - 1) / kBlock, (uint64_t)c->n_cus * 4u);
       im.table.redo_paths(redo_grid, im.lds_bytes, c->stream, im.dev, fp, (uint32_t)redone, cnt, accum);
       HIP_TRY(hipGetLastError());
