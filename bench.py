@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--mega-grid", type=int, default=0, help="mega-spheres: side of the sphere grid (500 = one million spheres)")
+    ap.add_argument("--mega-view", choices=["across", "above"], default="across",
+                    help="mega-spheres: across = camera at (13, 6, 3), a sliver of the field in the frame; above = looking down on the whole field")
     ap.add_argument("--precision", choices=["f32", "f64", "both"], default="both",
                     help="both = f64 headline + f32 sub-record with its image error against the f64 frame")
     ap.add_argument("--pipeline", choices=["auto", "fused", "sorted", "persistent"], default="auto")
@@ -82,6 +84,10 @@ def main():
                     help="lib = the library's own rt_reduce_accum (RCCL communicator created through rt_comm_init, its id broadcast by "
                          "torch.distributed); torch = torch.distributed.reduce.  lib falls back to torch when the communicator cannot be made")
     ap.add_argument("--dump-accum", default="", help="rank 0 writes the headline precision's summed radiance (H x W x 3 float64, .npy) here")
+    ap.add_argument("--partition", choices=["samples", "bands"], default="samples",
+                    help="how N ranks share a frame: samples = every rank renders all pixels for a slice of the sample range; bands = every rank "
+                         "renders all samples for the rows of its bands (rt_render_params::band_*), bands dealt out in turn")
+    ap.add_argument("--band-rows", type=int, default=16, help="--partition bands: rows per band (a power of two)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the multi-rank path on a box with fewer GPUs than ranks (sums travel through host memory)")
     args = ap.parse_args()
@@ -116,7 +122,7 @@ def main():
     earth = os.path.join(REPO, "rust-raytracing_amd", "assets", "earthmap.ppm")
     t_scene = time.perf_counter()
     scene = rtamd.Scene(args.scene, width=args.width, aspect=args.aspect, spp=args.spp, depth=args.depth, earth_path=earth,
-                        mega_grid=args.mega_grid)
+                        mega_grid=args.mega_grid, mega_view=1 if args.mega_view == "above" else 0)
     t_scene = time.perf_counter() - t_scene
     W, H = scene.width, scene.height
     n_objects = int(scene.desc.n_objects)
@@ -124,25 +130,30 @@ def main():
     t_upload = time.perf_counter()
     ctx.upload(scene)
     t_upload = time.perf_counter() - t_upload
-    s0 = rank * args.spp // world
-    s1 = (rank + 1) * args.spp // world
+    if args.partition == "samples":
+        s0, s1, bands = rank * args.spp // world, (rank + 1) * args.spp // world, None
+    else:
+        s0, s1, bands = 0, args.spp, (args.band_rows, world, rank)
     # N > 1: the sums travel through the library's own communicator (rt_comm_init / rt_reduce_accum, RCCL over xGMI); the id that
     # rank 0 creates reaches the other ranks through torch.distributed, which also provides the barriers of the timing contract
     lib_reduce = False
     if dist is not None and args.backend == "nccl" and args.reduce == "lib":
-        ok = 1
+        # Every rank first finds out, on its own, whether the library can open RCCL (rt_comm_unique_id does nothing else that can fail),
+        # and the ranks agree on the answer BEFORE any of them enters rt_comm_init: that call is a collective, and a rank that went
+        # in alone would wait there for ever.
+        ok, cid = 1, None
         try:
-            box = [rtamd.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            ctx.comm_init(box[0], world, rank)
+            cid = rtamd.comm_unique_id()
         except Exception as e:  # noqa: BLE001 - any failure means: use torch's reduce instead, on every rank
             ok = 0
-            print("rank %d: rt_comm_init failed (%s); falling back to torch.distributed.reduce" % (rank, e), file=sys.stderr, flush=True)
+            print("rank %d: the library cannot open RCCL (%s); falling back to torch.distributed.reduce" % (rank, e), file=sys.stderr, flush=True)
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        lib_reduce = bool(flag.item())
-        if not lib_reduce and ok:
-            ctx.comm_destroy()
+        if bool(flag.item()):
+            box = [cid if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ctx.comm_init(box[0], world, rank)  # all ranks are in here together; a failure now is an error, not a fallback
+            lib_reduce = True
     rgb_host = torch.zeros((H, W, 3), dtype=torch.uint8).pin_memory().numpy() if rank == 0 else None  # page-locked: the copy is one DMA
     persistent = args.pipeline in ("auto", "persistent")
 
@@ -165,7 +176,7 @@ def main():
             t_a = time.perf_counter()
             accum.zero_()
             torch.cuda.synchronize()  # the library renders on its own stream
-            st = ctx.render_accum(accum.data_ptr(), s0, s1, precision=prec, pipeline=pipe, samples_per_pass=args.samples_per_pass)
+            st = ctx.render_accum(accum.data_ptr(), s0, s1, precision=prec, pipeline=pipe, samples_per_pass=args.samples_per_pass, bands=bands)
             t_b = time.perf_counter()
             if dist is not None and lib_reduce:
                 ctx.reduce_accum(accum.data_ptr(), W, H, precision=prec, root=0)  # W*H*3 values, once per frame, stream idle on return
@@ -205,7 +216,9 @@ def main():
         kernel_ms = float(sum(s["bounce_kernel_ms"] for s in stats))
         launches = float(sum(s["bounce_kernel_launches"] for s in stats))
         rays_all, elapsed_max = rays, elapsed
-        per_rank = None
+        # split of a step (ms) on this rank: kernel, render call, reduce, resolve + copy
+        per_rank = [[round(kernel_ms / steps, 3), round(1e3 * split["render_s"] / steps, 3), round(1e3 * split["reduce_s"] / steps, 3),
+                     round(1e3 * split["resolve_s"] / steps, 3)]]
         if dist is not None:
             red_dev = dev if args.backend == "nccl" else torch.device("cpu")
             t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -214,7 +227,7 @@ def main():
             r = torch.tensor([rays], dtype=torch.float64, device=red_dev)
             dist.all_reduce(r, op=dist.ReduceOp.SUM)
             rays_all = float(r.item())
-            # per-rank split of a step (ms): kernel, render call, reduce, resolve + copy; rank 0 reports all of them
+            # rank 0 reports every rank's split
             mine = torch.tensor([kernel_ms / steps, 1e3 * split["render_s"] / steps, 1e3 * split["reduce_s"] / steps,
                                  1e3 * split["resolve_s"] / steps], dtype=torch.float64, device=red_dev)
             allr = [torch.zeros_like(mine) for _ in range(world)]
@@ -228,6 +241,8 @@ def main():
         return {"name": name, "walk": walk, "elapsed": elapsed_max, "rays": rays, "rays_all": rays_all, "kernel_ms": kernel_ms, "launches": launches,
                 "stats": stats, "rgb": None if rgb is None else rgb.copy(), "accum": accum, "split": split, "per_rank": per_rank}
 
+    scene_key = args.scene + ("-above" if args.scene == "mega-spheres" and args.mega_view == "above" else "")
+
     def roofline_of(leg, fpr):
         name = "f32" if leg["name"] == "f32" else "f64"  # the arithmetic; leg["name"] also tells the tree
         if fpr is None or leg["kernel_ms"] <= 0:
@@ -240,9 +255,9 @@ def main():
         issue = None
         try:  # counters of the same kernel on this frame, collected by tools/profile_round.sh (separate rocprofv3 passes)
             with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
-                t = json.load(f).get("%s_%s_%s" % (args.scene, leg["name"], "persistent" if persistent else args.pipeline))
+                t = json.load(f).get("%s_%s_%s" % (scene_key, leg["name"], "persistent" if persistent else args.pipeline))
             if t is not None:  # bytes per frame at the profiled sample count -> per launch of this run
-                traffic = t["bytes_per_frame"] * (args.spp / t["spp"]) * (s1 - s0) / args.spp / (leg["launches"] / max(1, args.steps))
+                traffic = t["bytes_per_frame"] * (args.spp / t["spp"]) * (leg["rays"] / max(1.0, leg["rays_all"])) / (leg["launches"] / max(1, args.steps))
                 with open(os.path.join(REPO, "profiles", "%s.json" % t["from"])) as f:
                     k = json.load(f)["kernels"]
                 k = k.get("k_paths_persistent") or k.get("k_paths_stepwise") or {}
@@ -267,19 +282,34 @@ def main():
         bpr = (32.0 * (leg["walk"][0] + leg["walk"][1]) + qb) if in_memory else qb
         hbm = {"bound": "hbm", "achieved": bpr * leg["rays"] / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": bpr * leg["rays"] / secs / 1e9 / HBM_PEAK_GBS, "bytes_per_ray": bpr}
-        main, other = (hbm, valu) if in_memory else (valu, hbm)
+        if in_memory:
+            # The lanes ask for `bpr` bytes per ray, and most of that is served by L2 and Infinity Cache; what reaches HBM is what the
+            # counters of the same kernel on the same frame saw (FETCH_SIZE, corrected, + WRITE_SIZE), and that - a fraction of the
+            # HBM peak that cannot exceed 1 - is what is priced here.  The request volume stays beside it.
+            hbm["requested_bytes_per_ray"] = bpr
+            hbm["requested_GBs"] = hbm["achieved"]
+            if traffic is not None:
+                per_ray = traffic * leg["launches"] / max(1.0, leg["rays"])
+                hbm.update({"achieved": per_ray * leg["rays"] / secs / 1e9, "frac": per_ray * leg["rays"] / secs / 1e9 / HBM_PEAK_GBS,
+                            "bytes_per_ray": per_ray, "source": "counter bytes of profiles/pmc_traffic.json scaled to this run's rays / this run's kernel time"})
+            else:
+                hbm.update({"achieved": None, "frac": None, "bytes_per_ray": None, "source": "no counter profile of this frame under profiles/"})
+        # the walk of a tree in memory is priced against HBM only where the counters show HBM carrying a fifth of its peak or more;
+        # below that the vector unit is the binding resource there too
+        hbm_bound = in_memory and hbm["frac"] is not None and hbm["frac"] >= 0.2
+        main, other = (hbm, valu) if hbm_bound else (valu, hbm)
         out = dict(main)
         if in_memory:
             out["walk"] = {"box_tests_per_ray": leg["walk"][0], "leaf_tests_per_ray": leg["walk"][1], "rays_sampled": leg["walk"][2]}
         out.update({
             "traffic": traffic, "kernel": kernel, "avg_launch_ms": leg["kernel_ms"] / max(1.0, leg["launches"]), "launches": leg["launches"],
             "issue": issue,
-            "note": ("the tree (tens of MB) lives in HBM / L2 / Infinity Cache and every lane fetches its own nodes: priced against the HBM "
-                     "roofline in algorithmic bytes (a rate above what `traffic` shows reaching HBM is served by the caches); valu = the same "
+            "note": ("the tree (tens of MB) lives in HBM / L2 / Infinity Cache and every lane fetches its own nodes; hbm = bytes that reached "
+                     "HBM by the counters against the 8 TB/s peak (requested_* = what the lanes asked the caches for); valu = the same "
                      "launches against the vector-ALU roofline" if in_memory else
                      "no dense contraction on this path (MFMA unused by design) and the scene is cache resident, so the vector ALU bounds it; "
                      "peak is the vector FMA peak of the dtype; hbm = the same launches against the HBM roofline"),
-            ("valu" if in_memory else "hbm"): other,
+            ("valu" if hbm_bound else "hbm"): other,
         })
         return out
 
@@ -307,7 +337,15 @@ def main():
             "vs_baseline": None,
             "dtype": head_name,
             "data": "synthetic",
-            "config": {"workload": "%s %dx%d, %d spp, depth %d, samples sharded over ranks, one reduce to rank 0" % (args.scene, W, H, args.spp, args.depth),
+            "config": {"workload": "%s %dx%d, %d spp, depth %d, %s, one reduce to rank 0" % (
+                           scene_key, W, H, args.spp, args.depth,
+                           "samples sharded over ranks" if args.partition == "samples" else "rows sharded over ranks in bands of %d" % args.band_rows),
+                       "partition": args.partition if args.partition == "samples" else "bands of %d rows" % args.band_rows,
+                       # what "f64" means here: IEEE double operations throughout; the small-scene kernels (flat walk) are compiled with
+                       # -ffp-contract=fast (a*b+c may fuse into one rounding) and take reciprocals and the Lambertian unit vector by
+                       # v_rcp / v_rsq + Newton steps (<= 11 / 19 ulp) where the reference divides and takes square roots
+                       "arithmetic": {"f64": "IEEE double; fp-contract=fast and refined rcp/rsq (<= 19 ulp) in the flat-walk kernels, fp-contract as written "
+                                             "and true quotients in the leaf tests of the four-wide walk", "f32": "tolerance mode"},
                        "pipeline": args.pipeline, "rays_per_step": head["rays_all"] / max(1, args.steps),
                        "rays_per_camera_sample": head["rays_all"] / max(1, args.steps) / (W * H * args.spp),
                        "lds_bytes": head["stats"][-1]["lds_bytes"], "scene_in_lds": head["stats"][-1]["scene_in_lds"],
@@ -315,7 +353,7 @@ def main():
         }
         if world > 1:
             out["config"]["reduce"] = "rt_reduce_accum (RCCL)" if lib_reduce else ("torch.distributed.reduce (%s)" % args.backend)
-            out["per_rank_ms"] = {"columns": ["kernel", "render_call", "reduce", "resolve_and_copy"], "ranks": head["per_rank"]}
+        out["per_rank_ms"] = {"columns": ["kernel", "render_call", "reduce", "resolve_and_copy"], "ranks": head["per_rank"]}
         cpu = None
         cnt = None
         if world == 1 and not args.no_cpu_baseline:
@@ -327,7 +365,7 @@ def main():
             if args.scene in ("earth", "final-scene"):
                 earth_rgb = rtamd.load_ppm(earth)
             osc = oracle_lib.OracleScene(args.scene, width=args.width, aspect=args.aspect, spp=args.spp, depth=args.depth, earth=earth_rgb,
-                                         mega_grid=args.mega_grid)
+                                         mega_grid=args.mega_grid, mega_view=1 if args.mega_view == "above" else 0)
             _, cnt, secs = osc.render(0, args.cpu_spp, seed=0, threads=threads)
             cpu = {"value": cnt["rays"] / secs / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
                    "sample": "same scene and frame, samples 0..%d of %d per pixel (%d rays), C++ f64 restatement of the reference with its "
@@ -384,7 +422,7 @@ def main():
                         "dissolved nested tree re-centred) and without the second tracing of rays that meet an exact tie",
             }
         if side is not None:
-            if world > 1:
+            if True:
                 out["f32"]["per_rank_ms"] = {"columns": ["kernel", "render_call", "reduce", "resolve_and_copy"], "ranks": side["per_rank"]}
         print(json.dumps(out), flush=True)
         if args.save and head["rgb"] is not None:

@@ -176,6 +176,13 @@ typedef struct rt_render_params {
   int32_t pipeline;                  /* RT_PIPELINE_* */
   uint32_t samples_per_pass;         /* queue pipelines: samples of every pixel traced together; 0 = choose */
   uint64_t seed;                     /* Philox counter words 2,3 */
+  /* Row bands (image-tile sharding, the static row split of src/render.rs:218-224,247-271 made interleaved): the frame's rows are
+   * cut into bands of `band_rows` rows (a power of two), band b belongs to the caller with b % band_stride == band_offset, and this
+   * call renders the rows of its own bands only (the other rows of `accum_dev` are not touched).  band_stride 0 or 1 = every row.
+   * Pixels keep their whole-frame index in the random streams, so the image does not depend on how the rows were shared out.
+   * PERSISTENT / AUTO pipeline only. */
+  uint32_t band_rows, band_stride, band_offset;
+  uint32_t pad;
 } rt_render_params;
 
 typedef struct rt_stats {

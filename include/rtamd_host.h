@@ -42,7 +42,8 @@ typedef struct rth_scene_opts {
   const uint8_t* earth_rgb; /* decoded earthmap.jpg (RGB8, row 0 on top) or NULL */
   int32_t earth_w, earth_h;
   int32_t mega_grid;  /* RTH_SCENE_MEGA_SPHERES only: a, b in [-grid, grid) */
-  int32_t pad;
+  int32_t mega_view;  /* RTH_SCENE_MEGA_SPHERES only: 0 = camera at (13, 6, 3) looking across the field (a sliver of it fills the frame);
+                         1 = camera 2.8 * grid above the centre looking straight down, the whole field in the frame */
   const char* earth_path; /* used when earth_rgb is NULL: binary PPM (P6) to load; NULL = "earthmap.ppm" in the CWD,
                              a missing file gives the reference's cyan fallback (src/texture.rs:106-110,131-133) */
 } rth_scene_opts;

@@ -37,6 +37,7 @@ struct SceneOpts {
   const uint8_t* earth;  // decoded earthmap RGB8 or null (-> cyan, texture.rs:131-133)
   int earth_w, earth_h;
   int mega_grid;      // SC_MEGA_SPHERES: a, b in [-grid, grid)
+  int mega_view;      // SC_MEGA_SPHERES: 1 = camera above the centre of the field, looking down
 };
 
 template <class R> struct Builder {
@@ -300,6 +301,10 @@ template <class R> std::unique_ptr<Scene<R>> build_scene(const SceneOpts& o) {  
       b.mega_spheres(o.mega_grid > 0 ? o.mega_grid : 500);
       sc.background = Background<R>{1, V3<R>(0.5, 0.7, 1.0), V3<R>(1, 1, 1)};
       look_from = V3<R>(13, 6, 3); v_fov = 40; aperture = (R)0.1;
+      if (o.mega_view == 1) {
+        const R h = (R)2.8 * (R)(o.mega_grid > 0 ? o.mega_grid : 500);
+        look_from = V3<R>(0, h, 0); v_up = V3<R>(0, 0, -1); focus_dist = h;
+      }
       sc.image_width = 3840; sc.samples_per_pixel = 1024;
       break;
     default: return nullptr;
@@ -430,8 +435,8 @@ static void first_hit_impl(const Scene<R>& sc, uint64_t seed, size_t n, const or
 extern "C" {
 
 orc_scene* orc_scene_create(int kind, int width, double aspect, int spp, int depth, uint64_t aux_seed, uint64_t bvh_seed,
-                            const uint8_t* earth, int earth_w, int earth_h, int mega_grid, int want_f32) {
-  SceneOpts o{kind, width, aspect, spp, depth, aux_seed, bvh_seed, earth, earth_w, earth_h, mega_grid};
+                            const uint8_t* earth, int earth_w, int earth_h, int mega_grid, int mega_view, int want_f32) {
+  SceneOpts o{kind, width, aspect, spp, depth, aux_seed, bvh_seed, earth, earth_w, earth_h, mega_grid, mega_view};
   auto* s = new orc_scene;
   s->d = build_scene<double>(o);
   if (!s->d) { delete s; return nullptr; }

@@ -56,6 +56,7 @@ int main(int argc, char** argv) {
     else if (a == "--device") cfg.device = std::atoi(need(i));
     else if (a == "--earth") cfg.scene.earth_path = need(i);
     else if (a == "--mega-grid") cfg.scene.mega_grid = std::atoi(need(i));
+    else if (a == "--mega-view") cfg.scene.mega_view = std::atoi(need(i));
     else if (a == "--precision") cfg.precision = std::strcmp(need(i), "f32") == 0 ? RT_PRECISION_F32 : RT_PRECISION_F64;
     else if (a == "--pipeline") {
       const char* v = need(i);

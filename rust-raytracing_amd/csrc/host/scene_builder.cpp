@@ -600,6 +600,10 @@ SceneData* build_scene(const rth_scene_opts& o) {  // src/scenes.rs:44-133
       mega_spheres(s, world, aux, o.mega_grid > 0 ? o.mega_grid : 500);
       gradient_bg();
       look_from = {13.0, 6.0, 3.0}; v_fov = 40.0; aperture = 0.1;
+      if (o.mega_view == 1) {  // from above: tan(20 deg) * 2.8 = 1.02 grids of half height, the field's 2 * grid square inside a 16:9 frame
+        const double h = 2.8 * (double)(o.mega_grid > 0 ? o.mega_grid : 500);
+        look_from = {0.0, h, 0.0}; v_up = {0.0, 0.0, -1.0}; focus_dist = h;
+      }
       s.image_width = 3840; s.spp = 1024;
       break;
     default:

@@ -133,6 +133,10 @@ struct FrameParams {
   // k_redo_paths; `redo_cap` entries of two words, the number of entries asked for in word 1 of the ray counter block.
   uint32_t* redo_list;
   uint32_t redo_cap;
+  // Row bands (rt_render_params::band_*): band_stride > 1 means that the launch renders only the rows of the bands b with
+  // b % band_stride == band_offset, bands being 1 << band_shift rows; n_pixels then counts the pixels of those rows and the feeder
+  // numbers them row after row ("local" rows), while `height` stays the frame's.
+  uint32_t band_shift, band_stride, band_offset;
 };
 
 struct Segment {
@@ -311,6 +315,11 @@ template <class R> struct PathFeeder {
           px_row = row + (wrap ? 1u : 0u);
         } else {
           pixel_row_col(st.pixel, fp.width, px_row, px_col);
+        }
+        if (fp.band_stride > 1u) {  // the same for every lane: local row -> row of the frame; the pixel keeps its whole-frame index
+          const uint32_t band = px_row >> fp.band_shift;
+          px_row = ((band * fp.band_stride + fp.band_offset) << fp.band_shift) + (px_row - (band << fp.band_shift));
+          st.pixel = px_row * fp.width + px_col;
         }
         st.sample = fp.sample_base + sample;
         if constexpr (MAKE_RAY) st.ray = primary_ray<R>(sc.camera, fp.width, fp.height, st.pixel, st.sample, fp.seed);

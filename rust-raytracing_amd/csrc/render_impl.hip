@@ -325,15 +325,24 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
                                          unsigned long long* host_rays) {
   using R4 = typename Vec4<R>::type;
   SceneImage<R>& im = image_of<R>(c);
-  const uint64_t n_pixels = (uint64_t)p.width * p.height;
+  const uint64_t frame_pixels = (uint64_t)p.width * p.height;
+  // rows this call renders: all of them, or those of its own bands (the last band of the frame may be short)
+  uint32_t own_rows = p.height, band_shift = 0;
+  const bool banded = p.band_stride > 1u;
+  if (banded) {
+    while ((1u << band_shift) < p.band_rows) ++band_shift;
+    own_rows = 0;
+    for (uint32_t y0 = p.band_offset << band_shift; y0 < p.height; y0 += p.band_stride << band_shift) own_rows += std::min(p.band_rows, p.height - y0);
+  }
+  const uint64_t n_pixels = (uint64_t)p.width * own_rows;
   const uint32_t n_samples = p.sample_end - p.sample_begin;
   auto t_begin = std::chrono::steady_clock::now();
   R* accum = reinterpret_cast<R*>(accum_dev);
   if (!accum) {
-    int rc = ensure_accum(c, n_pixels * 4 * sizeof(R));
+    int rc = ensure_accum(c, frame_pixels * 4 * sizeof(R));
     if (rc) return rc;
     accum = reinterpret_cast<R*>(c->accum);
-    HIP_TRY(hipMemsetAsync(accum, 0, n_pixels * 4 * sizeof(R), c->stream));
+    HIP_TRY(hipMemsetAsync(accum, 0, frame_pixels * 4 * sizeof(R), c->stream));
   }
   if (p.pipeline == RT_PIPELINE_PERSISTENT || p.pipeline == RT_PIPELINE_AUTO) {
     // one launch for the whole sample range; no ray queues
@@ -353,6 +362,7 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
     fp.n_samples = n_samples;
     fp.redo_list = c->d_redo;
     fp.redo_cap = kRedoCapacity;
+    fp.band_shift = band_shift; fp.band_stride = banded ? p.band_stride : 0u; fp.band_offset = banded ? p.band_offset : 0u;
     const unsigned long long total_paths = (unsigned long long)n_pixels * ((n_samples + chunk - 1) / chunk);  // units the path cursor counts
 #ifdef RT_STAMPS
     if (counters_override) return fail(RT_E_UNSUPPORTED, "the diagnostic build has no allocation-free entry point");
@@ -436,6 +446,7 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
     return RT_OK;
   }
   if (counters_override) return fail(RT_E_UNSUPPORTED, "the allocation-free entry point renders with the persistent pipeline only");
+  if (banded) return fail(RT_E_UNSUPPORTED, "row bands are rendered by the persistent pipeline only");
   uint32_t spp_pass = p.samples_per_pass ? p.samples_per_pass : (uint32_t)std::max<uint64_t>(1, kTargetPathsPerPass / n_pixels);
   spp_pass = std::max(1u, std::min(spp_pass, std::max(1u, n_samples)));
   if (n_pixels * spp_pass > 0x7FFFFFFFull) return fail(RT_E_INVALID, "width*height*samples_per_pass exceeds 2^31-1");

@@ -242,6 +242,10 @@ int check_render_params(const rt_context* c, const rt_render_params* p) {
   if (p->max_depth > kMaxDepth) return fail(RT_E_INVALID, "max_depth exceeds 4096");
   if ((p->precision & ~RT_F64_OWN_TREE) != RT_PRECISION_F32 && (p->precision & ~RT_F64_OWN_TREE) != RT_PRECISION_F64) return fail(RT_E_INVALID, "unknown precision");
   if (p->pipeline < RT_PIPELINE_AUTO || p->pipeline > RT_PIPELINE_PERSISTENT) return fail(RT_E_INVALID, "unknown pipeline");
+  if (p->band_stride > 1u) {
+    if (p->band_rows == 0u || (p->band_rows & (p->band_rows - 1u)) != 0u || p->band_rows > 32768u) return fail(RT_E_INVALID, "band_rows must be a power of two (1..32768)");
+    if (p->band_offset >= p->band_stride) return fail(RT_E_INVALID, "band_offset must be below band_stride");
+  }
   return RT_OK;
 }
 

@@ -46,7 +46,16 @@ class RtError(RuntimeError):
 class RenderParams(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32),
                 ("max_depth", C.c_uint32), ("precision", C.c_int32), ("pipeline", C.c_int32), ("samples_per_pass", C.c_uint32),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("band_rows", C.c_uint32), ("band_stride", C.c_uint32), ("band_offset", C.c_uint32), ("pad", C.c_uint32)]
+
+
+def band_rows(height, rows, stride, offset):
+    """Rows of a frame of `height` rows that belong to caller `offset` of `stride` when bands of `rows` rows are dealt out in turn
+    (rt_render_params::band_rows / band_stride / band_offset)."""
+    if stride <= 1:
+        return np.arange(height)
+    y = np.arange(height)
+    return y[(y // rows) % stride == offset]
 
 
 class Stats(C.Structure):
@@ -62,7 +71,7 @@ class Stats(C.Structure):
 class SceneOpts(C.Structure):
     _fields_ = [("scene", C.c_int32), ("width", C.c_int32), ("aspect", C.c_double), ("spp", C.c_int32), ("depth", C.c_int32),
                 ("aux_seed", C.c_uint64), ("bvh_seed", C.c_uint64), ("earth_rgb", C.c_void_p), ("earth_w", C.c_int32),
-                ("earth_h", C.c_int32), ("mega_grid", C.c_int32), ("pad", C.c_int32), ("earth_path", C.c_char_p)]
+                ("earth_h", C.c_int32), ("mega_grid", C.c_int32), ("mega_view", C.c_int32), ("earth_path", C.c_char_p)]
 
 
 class RenderConfig(C.Structure):
@@ -160,13 +169,13 @@ def _p(a):
 class Scene:
     """SceneConfig::get_scene (src/scenes.rs:44-133) through the C++ host library."""
 
-    def __init__(self, name, width=0, aspect=0.0, spp=0, depth=0, aux_seed=1, bvh_seed=7, earth=None, earth_path=None, mega_grid=0):
+    def __init__(self, name, width=0, aspect=0.0, spp=0, depth=0, aux_seed=1, bvh_seed=7, earth=None, earth_path=None, mega_grid=0, mega_view=0):
         _, H = load_libraries()
         self.name = name
         o = SceneOpts()
         o.scene = SCENES[name] if isinstance(name, str) else int(name)
         o.width, o.aspect, o.spp, o.depth = width, float(aspect), spp, depth
-        o.aux_seed, o.bvh_seed, o.mega_grid = aux_seed, bvh_seed, mega_grid
+        o.aux_seed, o.bvh_seed, o.mega_grid, o.mega_view = aux_seed, bvh_seed, mega_grid, mega_view
         self._earth = None
         if earth is not None:
             self._earth = np.ascontiguousarray(earth, dtype=np.uint8)
@@ -245,7 +254,7 @@ class Context:
         _check(self.L.rt_upload_scene(self.h, ptr))
         self.scene = scene
 
-    def _params(self, width, height, s_begin, s_end, depth, precision, pipeline, samples_per_pass, seed):
+    def _params(self, width, height, s_begin, s_end, depth, precision, pipeline, samples_per_pass, seed, bands=None):
         sc = self.scene
         p = RenderParams()
         p.width = width or sc.width
@@ -253,14 +262,16 @@ class Context:
         p.sample_begin, p.sample_end = s_begin, s_end
         p.max_depth = depth if depth is not None else sc.depth
         p.precision, p.pipeline, p.samples_per_pass, p.seed = precision, pipeline, samples_per_pass, seed
+        if bands is not None:  # (rows per band, number of callers sharing the frame, this caller's index)
+            p.band_rows, p.band_stride, p.band_offset = bands
         return p
 
     def render(self, s_begin=0, s_end=None, precision=F64, pipeline=PIPELINE_AUTO, seed=0, samples_per_pass=0, depth=None, width=0,
-               height=0, want_accum=True, want_rgb=True):
+               height=0, want_accum=True, want_rgb=True, bands=None):
         """rt_render: returns (rgb8[H,W,3] or None, accum[H,W,3] float64 or None, stats dict)."""
         if s_end is None:
             s_end = self.scene.spp
-        p = self._params(width, height, s_begin, s_end, depth, precision, pipeline, samples_per_pass, seed)
+        p = self._params(width, height, s_begin, s_end, depth, precision, pipeline, samples_per_pass, seed, bands)
         rgb = np.zeros((p.height, p.width, 3), dtype=np.uint8) if want_rgb else None
         acc = np.zeros((p.height, p.width, 3), dtype=np.float64) if want_accum else None
         st = Stats()
@@ -268,9 +279,9 @@ class Context:
         return rgb, acc, st.as_dict()
 
     def render_accum(self, accum_dev_ptr, s_begin, s_end, precision=F64, pipeline=PIPELINE_AUTO, seed=0, samples_per_pass=0, depth=None,
-                     width=0, height=0):
+                     width=0, height=0, bands=None):
         """rt_render_accum into a caller-owned DEVICE buffer (address as int) or the context's own (None)."""
-        p = self._params(width, height, s_begin, s_end, depth, precision, pipeline, samples_per_pass, seed)
+        p = self._params(width, height, s_begin, s_end, depth, precision, pipeline, samples_per_pass, seed, bands)
         st = Stats()
         _check(self.L.rt_render_accum(self.h, C.byref(p), C.c_void_p(accum_dev_ptr) if accum_dev_ptr else None, C.byref(st)))
         return st.as_dict()
@@ -413,6 +424,7 @@ def render_and_save(scene, output, device=0, precision=F64, pipeline=PIPELINE_AU
     cfg.scene.aux_seed = scene_kw.get("aux_seed", 1)
     cfg.scene.bvh_seed = scene_kw.get("bvh_seed", 7)
     cfg.scene.mega_grid = scene_kw.get("mega_grid", 0)
+    cfg.scene.mega_view = scene_kw.get("mega_view", 0)
     ep = scene_kw.get("earth_path")
     cfg.scene.earth_path = ep.encode() if ep else None
     cfg.output = output.encode()

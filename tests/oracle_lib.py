@@ -61,7 +61,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.orc_scene_create.restype = C.c_void_p
         L.orc_scene_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int,
-                                       C.c_int, C.c_int, C.c_int]
+                                       C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_scene_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 6
         L.orc_scene_camera.argtypes = [C.c_void_p, C.c_void_p]
@@ -102,7 +102,7 @@ def _p(a):
 class OracleScene:
     """A scene built by the oracle's own restatement of scenes.rs."""
 
-    def __init__(self, name, width=0, aspect=0.0, spp=0, depth=0, aux_seed=1, bvh_seed=7, earth=None, mega_grid=0, want_f32=False):
+    def __init__(self, name, width=0, aspect=0.0, spp=0, depth=0, aux_seed=1, bvh_seed=7, earth=None, mega_grid=0, want_f32=False, mega_view=0):
         self.name = name
         self._earth = None
         ep, ew, eh = None, 0, 0
@@ -110,7 +110,7 @@ class OracleScene:
             self._earth = np.ascontiguousarray(earth, dtype=np.uint8)
             eh, ew = self._earth.shape[:2]
             ep = _p(self._earth)
-        self.h = lib().orc_scene_create(SCENES[name], width, float(aspect), spp, depth, aux_seed, bvh_seed, ep, ew, eh, mega_grid,
+        self.h = lib().orc_scene_create(SCENES[name], width, float(aspect), spp, depth, aux_seed, bvh_seed, ep, ew, eh, mega_grid, mega_view,
                                         1 if want_f32 else 0)
         if not self.h:
             raise RuntimeError("orc_scene_create failed")

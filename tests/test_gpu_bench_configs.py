@@ -119,12 +119,14 @@ def test_frame_sums_at_1080p_rows(gpu, rtamd, oracle):
     assert (np.abs(got - want) / (np.abs(want) + 1e-3)).max() < 1e-9
 
 
-def test_million_spheres_at_3840x2160_against_the_oracle(gpu, rtamd, oracle):
-    """The synthetic large scene as configured: one million spheres (mega_grid = 500), 3840x2160.  Oracle and host library build
+@pytest.mark.parametrize("view", [0, 1])
+def test_million_spheres_at_3840x2160_against_the_oracle(gpu, rtamd, oracle, view):
+    """The synthetic large scene as configured: one million spheres (mega_grid = 500), 3840x2160, under both of its cameras (0: across
+    the field, 1: straight down on all of it, every sphere smaller than a pixel).  Oracle and host library build
     the same million spheres and the same reference tree independently.  First hits of 100 000 camera rays of the 4K frame:
     double precision (the library's four-wide tree, the reference's leaf arithmetic) identical to the oracle in every id, single
     precision identical outside ties; then one whole 4K frame in each precision."""
-    hs, os_ = make_pair(rtamd, oracle, "mega-spheres", width=3840, aspect=16.0 / 9.0, spp=1, mega_grid=500)
+    hs, os_ = make_pair(rtamd, oracle, "mega-spheres", width=3840, aspect=16.0 / 9.0, spp=1, mega_grid=500, mega_view=view)
     assert (hs.width, hs.height) == (3840, 2160) and os_.n_objects == 1_000_001
     gpu.upload(hs)
     rng = np.random.default_rng(500)

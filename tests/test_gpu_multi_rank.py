@@ -56,13 +56,63 @@ def _bench(args, nproc, tmp):
     return json.loads(line[0])
 
 
-def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
-    """bench.py's whole step - render the rank's sample range with the HIP kernels, reduce, resolve - with two ranks (fresh
-    processes, both on GPU 0, gloo) against one rank: the summed radiance agrees to 1e-12 in f64 (sample streams are keyed by
-    the global sample index; only the order of additions differs) and the f32 leg to 1e-5."""
-    common = ["--width", "160", "--spp", "8", "--scene", "cornell-box"]
+@pytest.mark.parametrize("name,kw,prec_name", [("cornell-box", dict(width=160, aspect=16 / 9, spp=6), "F64"), ("cornell-box", dict(width=160, aspect=16 / 9, spp=6), "F32"),
+                                               ("final-scene", dict(width=120, aspect=4 / 3, spp=3), "F64"), ("random", dict(width=208, spp=4), "F32"),
+                                               ("two-spheres", dict(width=96, spp=40), "F64")])
+def test_row_bands_tile_the_frame(gpu, rtamd, earth_rgb, name, kw, prec_name):
+    """rt_render_params::band_*: three callers share a frame whose height is not a multiple of the band (90 rows in bands of 16).
+    Each call fills the rows of its own bands and leaves every other row of the buffer as it was; the three together equal the
+    frame rendered in one call up to the order of the additions (pixels keep their whole-frame index in the random streams).
+    Covers the flat-walk kernel, the per-lane-walk kernel and the kernel that sums chunks of samples in registers."""
+    torch = pytest.importorskip("torch")
+    prec = getattr(rtamd, prec_name)
+    sc = rtamd.Scene(name, earth=earth_rgb if name == "final-scene" else None, **kw)
+    gpu.upload(sc)
+    W, H, spp = sc.width, sc.height, sc.spp
+    assert H % 16 != 0
+    dt = torch.float64 if prec_name == "F64" else torch.float32
+    whole = torch.zeros(H * W * 4, dtype=dt, device="cuda:0")
+    torch.cuda.synchronize()
+    st_whole = gpu.render_accum(whole.data_ptr(), 0, spp, precision=prec, seed=5)
+    parts = torch.zeros_like(whole)
+    torch.cuda.synchronize()
+    rays = cams = 0
+    seen = np.zeros(H, dtype=bool)
+    for k in (2, 0, 1):
+        st = gpu.render_accum(parts.data_ptr(), 0, spp, precision=prec, seed=5, bands=(16, 3, k))
+        rows = rtamd.band_rows(H, 16, 3, k)
+        assert st["camera_rays"] == len(rows) * W * spp and st["kernel_variant"] == st_whole["kernel_variant"]
+        seen[rows] = True
+        filled = (parts.view(H, W, 4)[:, :, :3].abs().sum(dim=(1, 2)) > 0).cpu().numpy()
+        assert not (filled & ~seen).any(), (k, np.nonzero(filled & ~seen)[0])  # rows of other callers' bands stay untouched
+        assert filled[rows].mean() > 0.8  # (a frame may have some black rows of its own)
+        rays += st["rays"]
+        cams += st["camera_rays"]
+    assert seen.all() and cams == W * H * spp
+    a, b = whole.view(H, W, 4)[:, :, :3].double().cpu().numpy(), parts.view(H, W, 4)[:, :, :3].double().cpu().numpy()
+    if prec_name == "F64":
+        assert rays == st_whole["rays"]
+        assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(a).max())
+    else:  # single precision adds in a different order round differently, nothing more
+        assert abs(rays - st_whole["rays"]) <= 1e-6 * st_whole["rays"] + 2
+        assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max())
+    with pytest.raises(rtamd.RtError):
+        gpu.render_accum(parts.data_ptr(), 0, spp, precision=prec, bands=(12, 3, 0))  # not a power of two
+    with pytest.raises(rtamd.RtError):
+        gpu.render_accum(parts.data_ptr(), 0, spp, precision=prec, bands=(16, 3, 3))  # offset out of range
+    with pytest.raises(rtamd.RtError):
+        gpu.render_accum(parts.data_ptr(), 0, spp, precision=prec, bands=(16, 3, 0), pipeline=rtamd.PIPELINE_FUSED)
+
+
+@pytest.mark.parametrize("partition", ["samples", "bands"])
+def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, partition):
+    """bench.py's whole step - render the rank's share (a slice of the sample range, or the rows of its bands) with the HIP kernels,
+    reduce, resolve - with two ranks (fresh processes, both on GPU 0, gloo) against one rank: the summed radiance agrees to 1e-12
+    in f64 (streams are keyed by whole-frame pixel and global sample index; only the order of additions differs), the f32 leg to 1e-5."""
+    common = ["--width", "160", "--spp", "8", "--scene", "cornell-box", "--partition", partition, "--band-rows", "8"]
     one = _bench(common + ["--dump-accum", str(tmp_path / "one.npy")], 1, str(tmp_path))
     two = _bench(common + ["--backend", "gloo", "--dump-accum", str(tmp_path / "two.npy")], 2, str(tmp_path))
+    assert two["config"]["partition"].startswith(partition)
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["dtype"] == "f64"
     assert two["config"]["rays_per_step"] == one["config"]["rays_per_step"]
     a, b = np.load(tmp_path / "one.npy"), np.load(tmp_path / "two.npy")

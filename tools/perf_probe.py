@@ -15,7 +15,7 @@ width = int(sys.argv[5]) if len(sys.argv) > 5 else 1920
 pipe = int(os.environ.get("PROBE_PIPELINE", "0"))
 ctx = rtamd.Context(0)
 sc = rtamd.Scene(scene, width=width, aspect=16.0 / 9.0, spp=spp, earth_path=os.path.join(REPO, "rust-raytracing_amd/assets/earthmap.ppm"),
-                 mega_grid=int(os.environ.get("PROBE_MEGA", "0")))
+                 mega_grid=int(os.environ.get("PROBE_MEGA", "0")), mega_view=int(os.environ.get("PROBE_MEGA_VIEW", "0")))
 t_up = time.time()
 ctx.upload(sc)
 print("scene: %d objects, %d nodes, upload %.2f s" % (len(sc.objects()), len(sc.nodes()), time.time() - t_up), flush=True)
