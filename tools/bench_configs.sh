@@ -17,4 +17,5 @@ run --scene random --spp 64 --no-cpu-baseline
 run --scene final-scene --spp 64 --no-cpu-baseline
 run --scene two-spheres --spp 256 --cpu-spp 8
 run --scene mega-spheres --mega-grid 500 --width 3840 --spp 16 --cpu-spp 1
+run --scene mega-spheres --mega-grid 500 --width 3840 --spp 16 --cpu-spp 1 --mega-view above
 echo done
