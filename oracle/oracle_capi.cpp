@@ -345,8 +345,9 @@ V3<R> sample_radiance(const Scene<R>& sc, uint32_t W, uint32_t H, uint32_t i, ui
   Stream cam(seed, pixel, s, 0, STAGE_CAMERA);
   R u_rand = gen01_at<R>(cam, 0);
   R v_rand = gen01_at<R>(cam, 1);
-  R u = ((R)i + u_rand) / (R)(W - 1);
-  R v = ((R)j + v_rand) / (R)(H - 1);
+  const uint32_t less = g_mutation == MUT_DIVIDE_BY_W_H ? 0u : 1u;
+  R u = ((R)i + u_rand) / (R)(W - less);  // render.rs:232-233
+  R v = ((R)j + v_rand) / (R)(H - less);
   Ray<R> ray = sc.camera.get_ray(u, v, cam);
   ++g_cnt.camera_rays;
   if (ray_out) { *ray_out = ray; return V3<R>(); }
@@ -509,6 +510,8 @@ double orc_render(const orc_scene* s, uint32_t s_begin, uint32_t s_end, uint64_t
   if (counters) std::memcpy(counters, &total, sizeof(Counters));
   return std::chrono::duration<double>(t1 - t0).count();
 }
+// 0 = the reference's behaviour; 1..3 = a deliberate fault (orc::Mutation) that the known-answer tests must notice
+void orc_set_mutation(int m) { g_mutation = m; }
 int orc_counters_len(void) { return (int)(sizeof(Counters) / sizeof(uint64_t)); }
 
 // Per-sample radiance for selected (pixel, sample) pairs: 4 doubles each = r, g, b, closest-hit queries of the path.

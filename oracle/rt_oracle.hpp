@@ -982,6 +982,9 @@ inline void color_to_rgb(const double sum[3], uint32_t spp, uint8_t out[3]) {  /
 // ---------------------------------------------------------------------------
 // render.rs:149-177 ray_color
 // ---------------------------------------------------------------------------
+// Deliberate faults (mutation checks of the test suite: each must make a known-answer test fail; 0 = the reference's behaviour).
+enum Mutation { MUT_NONE = 0, MUT_ONE_SIDED_LIGHT = 1, MUT_DIVIDE_BY_W_H = 2, MUT_TMIN_ZERO = 3 };
+inline int g_mutation = MUT_NONE;
 struct PathKey {
   uint64_t seed;
   uint32_t pixel, sample;
@@ -1000,7 +1003,7 @@ V3<R> ray_color(const Ray<R>& ray, const Background<R>& bg, const Hittable<R>& w
   Stream media(k.seed, k.pixel, k.sample, bounce, STAGE_MEDIA);
   HitCtx ctx{&media};
   HitRecord<R> rec;
-  const bool was_hit = world.hit(ray, (R)0.001, std::numeric_limits<R>::infinity(), rec, ctx);
+  const bool was_hit = world.hit(ray, g_mutation == MUT_TMIN_ZERO ? (R)0 : (R)0.001, std::numeric_limits<R>::infinity(), rec, ctx);
   if (g_path_trace) {
     PathVertex v{{(double)ray.origin[0], (double)ray.origin[1], (double)ray.origin[2]},
                  {(double)ray.direction[0], (double)ray.direction[1], (double)ray.direction[2]},
@@ -1009,6 +1012,7 @@ V3<R> ray_color(const Ray<R>& ray, const Background<R>& bg, const Hittable<R>& w
   }
   if (!was_hit) return bg.color(ray.direction);
   V3<R> emitted = rec.material->emitted(rec.u, rec.v, rec.p);
+  if (g_mutation == MUT_ONE_SIDED_LIGHT && !rec.front_face) emitted = V3<R>();
   Stream sc(k.seed, k.pixel, k.sample, bounce, STAGE_SCATTER);
   auto res = rec.material->scatter(ray, rec, sc);
   if (!res) return emitted;

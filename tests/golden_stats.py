@@ -11,7 +11,12 @@ What each image can pin (README.md:24-32 shows them; nothing ties them to the co
   simple_light.png  Perlin tables again, but the image is dominated by the light's falloff: channel means and block means, loosely.
   random.png        1920x1080 (the committed constants give 400x225), albedos from the unseeded thread_rng (src/scenes.rs:172,185):
                     channel means and the block means of the sky / ground structure, loosely.
-Bands are about twice the deviation seen over different table / albedo seeds of the oracle.
+Bands: tools/pin_noise.py renders every scene under eight seeds for what the reference draws from the unseeded thread_rng and
+records, per block of the 9x16 grid, the spread of the block mean over those seeds (tests/golden/block_spread.json; its printout
+is kept as profiles/r3_pin_noise.txt).  A block of the image may differ from a render by FLOOR + 4 x that spread: blocks that no
+seed touches (sky, far ground, the big spheres' surroundings in random.png; everything outside the marble in simple_light.png) are
+pinned at the floor, 0.012 of full scale (three to four times what those blocks measure against the images: <= 0.003 for
+random.png, <= 0.004 for simple_light.png), and blocks that depend on the seeds as loosely as the seeds make them.
 """
 import json
 import os
@@ -19,14 +24,21 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+FLOOR = 0.012
 
-# scene name -> (fixture, band on the 8-bit channel means, band on 9x16 block means of linear radiance or None)
+# scene name -> (fixture, band on the 8-bit channel means or None)
 FIXTURES = {
-    "earth": ("earth_stats.json", None, 0.04),                 # globe blocks only, see globe_blocks()
-    "two-perlin-spheres": ("perlin_stats.json", 9.0, None),
-    "simple-light": ("simple_light_stats.json", 3.5, 0.12),
-    "random": ("random_stats.json", 9.0, 0.45),
+    "earth": ("earth_stats.json", None),                # globe blocks only, see globe_blocks()
+    "two-perlin-spheres": ("perlin_stats.json", 9.0),
+    "simple-light": ("simple_light_stats.json", 1.5),   # spread over seeds 0.28, image - render 0.13
+    "random": ("random_stats.json", 8.0),               # spread over seeds 1.8, image - render up to 2.3
 }
+
+
+def block_band(name):
+    with open(os.path.join(HERE, "golden", "block_spread.json")) as f:
+        sd = np.array(json.load(f)[name]["block_std_worst_channel"])
+    return FLOOR + 4.0 * sd
 
 
 def load(name):
@@ -55,7 +67,7 @@ def globe_blocks():
 def check(name, rgb):
     """Asserts the bands of FIXTURES[name]; returns the measured deviations for printing."""
     g = load(name)
-    _, mean_band, block_band = FIXTURES[name]
+    _, mean_band = FIXTURES[name]
     m8, blocks = image_stats(rgb)
     ref_blocks = np.array(g["block_means_linear"])
     out = {"mean8": m8, "ref_mean8": np.array(g["mean_8bit"])}
@@ -66,7 +78,7 @@ def check(name, rgb):
         assert inside.sum() >= 12
         d = np.abs(blocks - ref_blocks)[inside]
         out["globe_block_max"] = d.max()
-        assert d.max() < block_band, (name, d.max())
+        assert d.max() < 0.03, (name, d.max())  # measured 0.022: a JPEG of a render through this library's own decode of the texture
         # the sky: the committed constant (0.70, 0.80, 1.00), clamped and quantised by color_to_rgb
         sky = blocks[0, 0]
         want = (np.floor(256 * np.minimum(np.sqrt([0.70, 0.80, 1.00]), 0.999)) / 256.0) ** 2
@@ -74,8 +86,24 @@ def check(name, rgb):
         # ... which is NOT the reference image's sky (a gradient): recorded so that a change of either side shows up
         out["sky_vs_image"] = np.abs(sky - ref_blocks[0, 0]).max()
         assert 0.01 < out["sky_vs_image"] < 0.08
-    elif block_band is not None:
-        d = np.abs(blocks - ref_blocks)
+    elif name == "two-perlin-spheres":
+        # sky blocks (no seed changes them): the committed constant, as for earth, and NOT the image's gradient sky
+        band = block_band(name)
+        sky = band <= FLOOR
+        assert sky.sum() >= 16
+        want = (np.floor(256 * np.minimum(np.sqrt([0.70, 0.80, 1.00]), 0.999)) / 256.0) ** 2
+        assert np.abs(blocks[sky] - want).max() < 0.005, np.abs(blocks[sky] - want).max()
+        out["sky_vs_image"] = np.abs(blocks - ref_blocks).max(axis=2)[sky].max()
+        assert 0.03 < out["sky_vs_image"] < 0.08
+        # the marble: as loosely as the seeds make it
+        d = np.abs(blocks - ref_blocks).max(axis=2)
+        assert (d[~sky] < band[~sky] + 0.06).all(), (name, (d - band)[~sky].max())
+    else:
+        band = block_band(name)
+        d = np.abs(blocks - ref_blocks).max(axis=2)
         out["block_max"] = d.max()
-        assert d.max() < block_band, (name, d.max())
+        out["pinned_blocks"] = int((band <= FLOOR + 0.012).sum())
+        out["pinned_block_max"] = d[band <= FLOOR + 0.012].max()
+        assert (d < band).all(), (name, np.argwhere(d >= band).tolist(), (d - band).max())
+        assert out["pinned_blocks"] >= (30 if name == "random" else 80)
     return out

@@ -198,6 +198,26 @@ class OracleScene:
         return out
 
 
+MUTATIONS = {"none": 0, "one-sided-light": 1, "divide-by-w-h": 2, "tmin-zero": 3}
+
+
+class mutation:
+    """Context manager: the oracle with one deliberate fault switched on (a check of the tests, not of the oracle):
+    one-sided-light = DiffuseLight emits from its front face only (the reference: both, src/material.rs:160-162);
+    divide-by-w-h = pixel coordinates divided by W and H (the reference: W - 1 and H - 1, src/render.rs:232-233);
+    tmin-zero = closest-hit interval opens at 0 (the reference: 0.001, src/render.rs:158)."""
+
+    def __init__(self, name):
+        self.kind = MUTATIONS[name]
+
+    def __enter__(self):
+        lib().orc_set_mutation(self.kind)
+
+    def __exit__(self, *exc):
+        lib().orc_set_mutation(0)
+        return False
+
+
 def resolve(accum, spp):
     accum = np.ascontiguousarray(accum, dtype=np.float64)
     rgb = np.zeros(accum.shape, dtype=np.uint8)

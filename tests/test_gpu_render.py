@@ -141,23 +141,38 @@ def test_full_size_headline_config_properties(gpu, rtamd):
     assert abs(s32["rays"] - s64["rays"]) / s64["rays"] < 5e-3
 
 
-def test_cornell_matches_reference_sample_render(gpu, rtamd):
-    """Statistical golden from the reference's own committed render cornell_box.png (600x600, scene defaults):
-    8x8 block means of clamped linear radiance (tests/golden/cornell_box_png_stats.json)."""
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_cornell_matches_reference_sample_render(gpu, rtamd, precision):
+    """Statistical golden from the reference's own committed render cornell_box.png (600x600, 200 samples, the scene's defaults):
+    channel means and 8x8 block means of linear radiance (tests/golden/cornell_box_png_stats.json), both sides taken from 8-bit
+    pixels the same way.  The image is one 200-sample draw; sixteen 200-sample frames of this library, each clamped and quantised
+    as the image was, give the expectation of that statistic to a quarter of the draw's own noise.  Measured (tools/pin_noise.py,
+    profiles/r3_pin_noise.txt): a block mean scatters by 0.0016 from seed to seed (worst block), channel means by 0.1 %; the image
+    lies within 0.0033 / 0.15 % of the sixteen-frame mean.  Bands: 3.2 standard deviations of the image's own draw on the mean of
+    the frames (0.005, 0.4 %), and on every single frame against the image 3.5 standard deviations of a difference of two draws
+    (0.008, 0.6 %)."""
     import json
     import os
     with open(os.path.join(os.path.dirname(__file__), "golden", "cornell_box_png_stats.json")) as f:
         g = json.load(f)
+    ref_m, ref_b = np.array(g["mean_linear"]), np.array(g["block_means_linear"])
     hs = rtamd.Scene("cornell-box")
     assert (hs.width, hs.height, hs.spp) == (600, 600, 200)
     gpu.upload(hs)
-    rgb, acc, _ = gpu.render(0, 200, precision=rtamd.F32, seed=123)
-    lin = (rgb.astype(np.float64) / 256.0) ** 2  # same transform the fixture applied to the PNG
-    blocks = lin.reshape(8, 75, 8, 75, 3).mean(axis=(1, 3))
-    ref = np.array(g["block_means_linear"])
-    assert np.abs(lin.reshape(-1, 3).mean(0) - np.array(g["mean_linear"])).max() < 0.003
-    assert np.abs(blocks - ref).max() < 0.03
-    assert np.abs(rgb.reshape(-1, 3).mean(0) - np.array(g["mean_8bit"])).max() < 2.0
+    ms, bs = [], []
+    for seed in range(16):
+        rgb, _, _ = gpu.render(0, 200, precision=rtamd.F64 if precision == "f64" else rtamd.F32, seed=2000 + seed, want_accum=False)
+        lin = (rgb.astype(np.float64) / 256.0) ** 2  # same transform the fixture applied to the PNG
+        ms.append(lin.reshape(-1, 3).mean(0))
+        bs.append(lin.reshape(8, 75, 8, 75, 3).mean(axis=(1, 3)))
+        assert np.abs(rgb.reshape(-1, 3).mean(0) - np.array(g["mean_8bit"])).max() < 0.6
+    ms, bs = np.array(ms), np.array(bs)
+    print("\ncornell-box %s: mean of 16 frames vs image: channel means %s (relative), blocks %.5f; worst single frame %.5f / %.5f"
+          % (precision, np.round((ms.mean(0) - ref_m) / ref_m, 5), np.abs(bs.mean(0) - ref_b).max(), (np.abs(ms - ref_m) / ref_m).max(), np.abs(bs - ref_b).max()))
+    assert (np.abs(ms.mean(0) - ref_m) / ref_m).max() < 0.004
+    assert np.abs(bs.mean(0) - ref_b).max() < 0.005
+    assert (np.abs(ms - ref_m) / ref_m).max() < 0.006
+    assert np.abs(bs - ref_b).max() < 0.008
 
 
 @pytest.mark.parametrize("precision", ["f64", "f32"])
