@@ -244,3 +244,72 @@ def test_header_compiles_as_plain_c(tmp_path):
                            "-L", BUILD, "-lrtamd_host", "-lrtamd", "-Wl,-rpath," + BUILD, "-Wl,-rpath-link," + BUILD])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.split()[0] == str(len(names)) and "gfx950" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def _build_c_abi_smoke(tmp_path):
+    exe = tmp_path / "c_abi_smoke"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(REPO, "include"),
+                           os.path.join(REPO, "tests", "c_abi_smoke.c"), "-o", str(exe), "-L", BUILD, "-lrtamd", "-Wl,-rpath," + BUILD,
+                           "-Wl,-rpath-link,/opt/rocm/lib"])
+    return exe
+
+
+def test_c_program_links_and_checks_arguments(tmp_path):
+    """tests/c_abi_smoke.c - a C11 program that includes include/rtamd.h, fills an rt_scene_desc by hand and links librtamd.so -
+    compiles without warnings under -pedantic; its device-free part (argument checks, error string) runs here."""
+    exe = _build_c_abi_smoke(tmp_path)
+    r = subprocess.run([str(exe), "--no-gpu"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "c_abi_smoke ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+def test_c_program_renders_on_the_gpu(tmp_path):
+    """The same program, all of it: uploads its two-rectangle scene, renders 16x16 in both precisions on GPU 0 and checks status
+    codes, statistics and pixels - the C ABI with no Python in between."""
+    exe = _build_c_abi_smoke(tmp_path)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "c_abi_smoke ok", (r.returncode, r.stdout, r.stderr)
+
+
+def test_binding_layouts_match_the_header(rtamd, tmp_path):
+    """Every struct a binding has to mirror (the ctypes classes and numpy record types here, the #[repr(C)] structs of a Rust
+    host): size and the offset of every field as a C compiler lays out include/rtamd.h, against the Python mirrors - a field
+    added to the header without its mirror, or a pad forgotten, shows up here and not as a garbled render."""
+    ct = {"rt_render_params": rtamd.RenderParams, "rt_stats": rtamd.Stats, "rth_scene_opts": rtamd.SceneOpts, "rth_render_config": rtamd.RenderConfig}
+    dt = {"rt_bvh_node": rtamd.NODE_DTYPE, "rt_object": rtamd.OBJECT_DTYPE, "rt_shape": rtamd.SHAPE_DTYPE, "rt_material": rtamd.MATERIAL_DTYPE,
+          "rt_texture": rtamd.TEXTURE_DTYPE, "rt_ray": rtamd.RAY_DTYPE, "rt_hit": rtamd.HIT_DTYPE}
+    sizes = {"rt_scene_desc": ctypes.sizeof(rtamd.SceneDesc), "rt_camera": 24 * 8, "rt_background": 8 + 48, "rt_perlin": 256 * 24 + 3 * 1024,
+             "rt_image": 16, "rt_comm_id": 128}
+    lines = []
+    for cname, cls in ct.items():
+        lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        lines += ['printf(" %s=%%zu", offsetof(%s, %s));' % (f[0], cname, f[0]) for f in cls._fields_]
+        lines.append('printf("\\n");')
+    for cname, d in dt.items():
+        lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        cnames = {"o": "origin", "d": "direction", "n": "normal"}  # the record types abbreviate three names
+        lines += ['printf(" %s=%%zu", offsetof(%s, %s));' % (f, cname, cnames.get(f, f)) for f in d.names]
+        lines.append('printf("\\n");')
+    for cname in sizes:
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "rtamd.h"\n#include "rtamd_host.h"\nint main(void) {\n%s\nreturn 0;\n}\n' % "\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60).stdout.strip().splitlines()
+    assert len(out) == len(ct) + len(dt) + len(sizes)
+    for line in out:
+        cname, size, *fields = line.split()
+        if cname in ct:
+            cls = ct[cname]
+            assert ctypes.sizeof(cls) == int(size), (cname, ctypes.sizeof(cls), size)
+            for f in fields:
+                fname, off = f.split("=")
+                assert getattr(cls, fname).offset == int(off), (cname, fname, getattr(cls, fname).offset, off)
+        elif cname in dt:
+            assert dt[cname].itemsize == int(size), (cname, dt[cname].itemsize, size)
+            for f in fields:
+                fname, off = f.split("=")
+                assert dt[cname].fields[fname][1] == int(off), (cname, fname)
+        else:
+            assert sizes[cname] == int(size), (cname, sizes[cname], size)
