@@ -204,6 +204,7 @@ typedef struct rt_stats {
 #define RT_VARIANT_CHUNKED 2u          /* a lane sums up to 16 samples of one pixel before its one atomic add (cheap bright paths) */
 #define RT_VARIANT_STEPWISE 4u         /* k_paths_stepwise (per-lane tree walks) instead of k_paths_persistent */
 #define RT_VARIANT_DEFERRED_RECORDS 8u /* double precision on the caller's tree: hit record built once, after the walk */
+#define RT_VARIANT_DEVICE_TREE 16u     /* the tree the kernel walked was built on the GPU at upload (scenes of 100 000 objects and more) */
 
 typedef struct rt_context rt_context;
 

@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <thread>
 #include <unordered_map>
@@ -175,7 +176,43 @@ class FastTreeBuilder {
   }
   // out[o] = 1 for every object of `order` (objects in the order a walk visits them) that is an exact copy of an object coming
   // later in it.  `eligible(o)` says which objects take part.  Open-addressing table of (hash, last object with that signature).
+  // `sort_pairs` (optional): sorts (hash, position) pairs by hash, stably - the device's radix sort for scenes of a million objects,
+  // where filling a hash table from one thread is most of this search.
+  std::function<bool(uint64_t*, uint32_t*, size_t)> sort_pairs;
   template <class Pred> std::vector<char> earlier_copies(const std::vector<int>& order, Pred eligible) const {
+    size_t sort_min = 65536;  // RTAMD_SORT_MIN: another threshold (tests run the sorted search on small scenes)
+    if (const char* e = std::getenv("RTAMD_SORT_MIN")) sort_min = (size_t)std::max(1, atoi(e));
+    if (sort_pairs && order.size() >= sort_min) {
+      std::vector<uint64_t> key(order.size());
+      std::vector<uint32_t> pos(order.size());
+      parallel_chunks(order.size(), [&](size_t, size_t lo, size_t hi) {
+        for (size_t q = lo; q < hi; ++q) {
+          // objects that take no part sort to the end (their own hash value could collide with that marker; they are skipped by position)
+          key[q] = eligible(order[q]) ? ((uint64_t)SignatureHash()(signature(order[q])) >> 1) : ~0ull;
+          pos[q] = (uint32_t)q;
+        }
+      });
+      if (sort_pairs(key.data(), pos.data(), key.size())) {
+        std::vector<char> out((size_t)s_.n_objects, 0);
+        for (size_t a = 0; a < key.size();) {
+          size_t b = a + 1;
+          while (b < key.size() && key[b] == key[a]) ++b;
+          if (key[a] != ~0ull && b - a > 1) {
+            // equal hashes (positions ascending: the sort is stable): an object is an earlier copy when the LAST entry of the run
+            // with its signature is another object (the walk may visit an object's own leaf more than once)
+            for (size_t i = a; i < b; ++i) {
+              const Signature g = signature(order[pos[i]]);
+              size_t last = i;
+              for (size_t j = i + 1; j < b; ++j)
+                if (signature(order[pos[j]]) == g) last = j;
+              if (order[pos[last]] != order[pos[i]]) out[(size_t)order[pos[i]]] = 1;
+            }
+          }
+          a = b;
+        }
+        return out;
+      }
+    }
     size_t cap = 16;
     while (cap < 2 * order.size()) cap <<= 1;
     struct Slot { uint64_t hash; int obj; };
@@ -212,6 +249,11 @@ class FastTreeBuilder {
       if (eligible(o) && table[(size_t)slot_of[(size_t)o]].obj != o) out[(size_t)o] = 1;
     return out;
   }
+
+  // For the device-side builder (gpu_build.hip), which takes one box and one leaf word per object: what this builder would give
+  // the object as a leaf.  Only for scenes without nested trees, media and spheres of negative radius.
+  Box3d leaf_box(int o) const { return object_box(o); }
+  uint32_t word_of(int o) const { return leaf_word(o); }
 
  private:
 

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernel_table.h"
@@ -46,6 +47,7 @@ template <class R> struct SceneImage {
   int preset = PRESET_ALL_TOP;
   KernelTable<R> table{};
   uint32_t lds_bytes = 0;
+  bool device_built_tree = false;  // its four-wide tree came from gpu_build_wide()
 };
 
 struct TmpLink {
@@ -82,6 +84,27 @@ inline bool reads_leftover_uv(const rt_scene_desc& s) {
 }
 
 inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
+
+// Host threads this process may use for the upload's loops: the hardware's, capped by OMP_NUM_THREADS (a GPU box's CPU share is
+// far below the machine's core count) and by 16.
+inline unsigned upload_threads() {
+  unsigned hw = std::thread::hardware_concurrency();
+  if (const char* e = std::getenv("OMP_NUM_THREADS")) hw = std::min<unsigned>(hw ? hw : 1u, (unsigned)std::max(1, atoi(e)));
+  return std::max(1u, std::min(hw, 16u));
+}
+// fn(thread, lo, hi) over [0, n) in contiguous chunks, one per thread, in order (thread t gets the t-th chunk); small ranges run inline
+template <class Fn> void parallel_chunks(size_t n, Fn fn, size_t min_per_thread = 32768) {
+  const size_t n_threads = std::max<size_t>(1, std::min<size_t>(upload_threads(), n / std::max<size_t>(1, min_per_thread)));
+  if (n_threads <= 1) { fn((size_t)0, (size_t)0, n); return; }
+  const size_t per = (n + n_threads - 1) / n_threads;
+  std::vector<std::thread> pool;
+  for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(fn, t, std::min(n, t * per), std::min(n, (t + 1) * per));
+  fn((size_t)0, (size_t)0, std::min(n, per));
+  for (std::thread& t : pool) t.join();
+}
+inline size_t parallel_chunk_count(size_t n, size_t min_per_thread = 32768) {
+  return std::max<size_t>(1, std::min<size_t>(upload_threads(), n / std::max<size_t>(1, min_per_thread)));
+}
 
 }  // namespace rti
 
@@ -151,7 +174,13 @@ inline uint32_t grid_for(const rt_context* c, uint64_t n, uint32_t blocks_per_cu
 template <class R> void layout_sections(rtd::BlobLayout& lay);
 template <class R>
 int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink>& links, int root_link, const std::vector<int>& sub_root_of_object,
-                int preset, SceneImage<R>& im, const std::vector<WideTmp>* wide, const std::vector<uint32_t>* pre, bool exact);
+                int preset, SceneImage<R>& im, const std::vector<WideTmp>* wide, const std::vector<uint32_t>* pre, bool exact,
+                const rtd::WideNode* device_wide = nullptr, uint32_t n_device_wide = 0);
+// gpu_build.hip: (key, value) pairs in host memory sorted by key on the device (stable); for the upload's searches among a million hashes
+int gpu_sort_pairs(rt_context* c, uint64_t* keys, uint32_t* vals, size_t n);
+// gpu_build.hip: the four-wide tree over `n_leaves` boxes built on the device (a device array the caller frees)
+int gpu_build_wide(rt_context* c, const float* boxes, const uint32_t* words, size_t n_leaves, const double cen_lo[3], const double cen_hi[3],
+                   rtd::WideNode** wide_out, uint32_t* n_wide_out, int* stack_need_out);
 template <class R>
 int render_accum_impl(rt_context* c, const rt_render_params& p, void* accum_dev, rt_stats* stats, unsigned long long* counters_override = nullptr,
                       unsigned long long* host_rays = nullptr);

@@ -1,5 +1,6 @@
 // Host-side render loop and test entry points for both arithmetic types.  The kernels themselves are reached through
 // the per-preset launcher tables of kernel_table.h.
+#include <memory>
 #include <limits>
 #include "context.h"
 #include "kernel_table.h"
@@ -71,7 +72,8 @@ template <class R> void layout_sections(BlobLayout& lay) {
 
 template <class R>
 int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink>& links, int root_link, const std::vector<int>& sub_root_of_object,
-                int preset, SceneImage<R>& im, const std::vector<WideTmp>* wide, const std::vector<uint32_t>* pre, bool exact) {
+                int preset, SceneImage<R>& im, const std::vector<WideTmp>* wide, const std::vector<uint32_t>* pre, bool exact,
+                const WideNode* device_wide, uint32_t n_device_wide) {
   BlobLayout lay{};
   lay.n_links = (uint32_t)links.size();
   lay.n_objects = (uint32_t)s.n_objects;
@@ -118,16 +120,31 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
   layout_sections<R>(lay);
   // The four-wide form of the library's own tree replaces the threaded list where the image does not fit in LDS (there the list
   // is walked from LDS and is the faster of the two).  RTAMD_WIDE_ALWAYS=1: wherever a wide tree exists (measurement switch).
-  if (wide && !wide->empty() && (preset == PRESET_BALLS_LDS || preset == PRESET_FLATALL_LDS) &&
-      (lay.total_bytes > kLdsAllMax || getenv("RTAMD_WIDE_ALWAYS"))) {
+  // (a tree built on the device comes without a list: it is walked whatever the image's size)
+  const bool have_wide = device_wide ? n_device_wide > 0 : (wide && !wide->empty());
+  if (have_wide && (preset == PRESET_BALLS_LDS || preset == PRESET_FLATALL_LDS) &&
+      (lay.total_bytes > kLdsAllMax || device_wide || getenv("RTAMD_WIDE_ALWAYS"))) {
     // `exact`: the four-wide tree stands in for the list in `links` (the caller's tree): the kernels with the reference's leaf
     // arithmetic and tie rule (F_EXACT)
     preset = preset == PRESET_BALLS_LDS ? (exact ? PRESET_BALLS_WIDE_EXACT : PRESET_BALLS_WIDE) : (exact ? PRESET_FLATALL_WIDE_EXACT : PRESET_FLATALL_WIDE);
-    lay.n_wide = (uint32_t)wide->size();
+    lay.n_wide = device_wide ? n_device_wide : (uint32_t)wide->size();
     layout_sections<R>(lay);
+  } else if (device_wide) {
+    return fail(RT_E_INVALID, "internal error: a tree built on the device for a preset that does not walk it");
   }
-  std::vector<uint8_t> blob(lay.total_bytes, 0);
-  if (lay.n_wide) {
+  // the host's part of the blob: all of it, or everything in front of a four-wide tree that is already on the device
+  const bool wide_on_device = device_wide && lay.n_wide;
+  struct RawBlob {  // zero-filled on the host's threads (a std::vector would fill a quarter of a gigabyte from one)
+    std::unique_ptr<uint8_t[]> mem;
+    size_t bytes;
+    explicit RawBlob(size_t n) : mem(new uint8_t[n]), bytes(n) {
+      uint8_t* base = mem.get();
+      parallel_chunks(n, [base](size_t, size_t lo_, size_t hi_) { std::memset(base + lo_, 0, hi_ - lo_); }, (size_t)4 << 20);
+    }
+    uint8_t* data() { return mem.get(); }
+    size_t size() const { return bytes; }
+  } blob(wide_on_device ? lay.wide_off : lay.total_bytes);
+  if (lay.n_wide && !wide_on_device) {
     WideNode* W = reinterpret_cast<WideNode*>(blob.data() + lay.wide_off);
     const float inf = std::numeric_limits<float>::infinity();
     for (size_t i = 0; i < wide->size(); ++i) {
@@ -199,7 +216,8 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
       for (const FlatRect& r : frects[k]) *fr++ = r;
   }
   auto* L = reinterpret_cast<BoxLink*>(blob.data() + lay.links_off);  // single-precision boxes in both images (see BoxLink)
-  for (size_t i = 0; i < links.size(); ++i) {
+  parallel_chunks(links.size(), [&](size_t, size_t lo_, size_t hi_) {
+  for (size_t i = lo_; i < hi_; ++i) {
     for (int k = 0; k < 3; ++k) { L[i].bmin[k] = round_down<float>(links[i].bmin[k]); L[i].bmax[k] = round_up<float>(links[i].bmax[k]); }
     // A box that is inverted along some axis (the node of a lone sphere of negative radius, src/sphere.rs:75-81) fails the
     // reference's test for every ray (src/aabb.rs:38-45: t_max <= t_min on that axis).  It is stored as the point at +infinity,
@@ -213,9 +231,11 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
     // front_face rule lives in those flags (the single-precision walk reads them when it writes the record)
     if (!single && (links[i].hit & LEAF_FLAG) && (s.objects[links[i].hit & LEAF_INDEX_MASK].flags & OBJ_FRONT_CHAIN)) L[i].hit &= ~LEAF_SIMPLE;
   }
+  });
   auto* S = reinterpret_cast<DShape<R>*>(blob.data() + lay.shapes_off);
   auto* O = reinterpret_cast<DObject<R>*>(blob.data() + lay.objects_off);
-  for (int i = 0; i < s.n_objects; ++i) {
+  parallel_chunks((size_t)s.n_objects, [&](size_t, size_t lo_, size_t hi_) {
+  for (size_t i = lo_; i < hi_; ++i) {
     const rt_object& o = s.objects[i];
     S[i].obj_id = o.obj_id; S[i].sub_id = o.sub_id;
     if (o.flags & RT_OBJ_SUB_BVH) {
@@ -231,6 +251,7 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
     for (int k = 0; k < 3; ++k) O[i].offset[k] = (o.flags & RT_OBJ_TRANSLATE) ? (R)o.offset[k] : (R)0;  // subtracted unconditionally on the device
     O[i].sin_theta = (R)o.sin_theta; O[i].cos_theta = (R)o.cos_theta; O[i].neg_inv_density = (R)o.neg_inv_density;
   }
+  });
   auto* M = reinterpret_cast<DMaterial<R>*>(blob.data() + lay.materials_off);
   for (int i = 0; i < s.n_materials; ++i) {
     M[i].tag = s.materials[i].tag; M[i].texture = s.materials[i].texture;
@@ -265,8 +286,10 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
       for (int k = 0; k < 3; ++k) cr.f[3 * v + k] = (R)parts[v][k];
     cr.f[18] = (R)s.camera.lens_radius; cr.f[19] = (R)s.camera.shutter_open_time; cr.f[20] = (R)s.camera.shutter_close_time;
   }
-  HIP_TRY(hipMalloc((void**)&im.d_blob, blob.size()));
+  HIP_TRY(hipMalloc((void**)&im.d_blob, lay.total_bytes));
   HIP_TRY(hipMemcpy(im.d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+  if (wide_on_device) HIP_TRY(hipMemcpy(im.d_blob + lay.wide_off, device_wide, (size_t)lay.n_wide * sizeof(WideNode), hipMemcpyDeviceToDevice));
+  im.device_built_tree = wide_on_device;
   if (preset == PRESET_ALL_LDS && lay.total_bytes > kLdsAllMax) preset = PRESET_ALL_TOP;  // the f64 image is larger than the f32 one
   if (preset == PRESET_BALLS_LDS && lay.total_bytes > kLdsAllMax) preset = PRESET_BALLS_TOP;
   if (preset == PRESET_FLATALL_LDS && lay.total_bytes > kLdsAllMax) preset = PRESET_FLATALL_TOP;
@@ -440,7 +463,7 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
       stats->passes = 1;
       stats->lds_bytes = im.lds_bytes;
       stats->scene_in_lds = (uint32_t)im.preset;
-      stats->kernel_variant = variant;
+      stats->kernel_variant = variant | (im.device_built_tree ? RT_VARIANT_DEVICE_TREE : 0u);
       stats->paths_redone = redone;
     }
     return RT_OK;
@@ -636,7 +659,7 @@ template <class R> int resolve_impl(rt_context* c, const void* accum_dev, size_t
 #define RTI_INSTANTIATE(R)                                                                                                                   \
   template void layout_sections<R>(BlobLayout&);                                                                                        \
   template int build_image<R>(rt_context*, const rt_scene_desc&, const std::vector<TmpLink>&, int, const std::vector<int>&, int, SceneImage<R>&, \
-                              const std::vector<WideTmp>*, const std::vector<uint32_t>*, bool);                                                \
+                              const std::vector<WideTmp>*, const std::vector<uint32_t>*, bool, const WideNode*, uint32_t);                     \
   template int render_accum_impl<R>(rt_context*, const rt_render_params&, void*, rt_stats*, unsigned long long*, unsigned long long*);                                              \
   template int trace_batch_impl<R>(rt_context*, const rt_ray*, size_t, rt_hit*, uint64_t, int);                                                   \
   template int pairs_kernel_impl<R>(rt_context*, int, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint32_t*, size_t, uint64_t, void*, \

@@ -74,7 +74,13 @@ struct LinkBuilder {
   const std::vector<char>* splice = nullptr;
   // skip[o] != 0: object o is an exact copy of an object the walk visits later; its leaf is left out (see rt_upload_scene)
   const std::vector<char>* skip = nullptr;
-  explicit LinkBuilder(const rt_scene_desc& sc) : s(sc), node_seen((size_t)std::max(0, sc.n_nodes), 0) {}
+  // objects in the order their leaves are emitted: a node emits its second subtree before its first (the first one's entries need
+  // to know where the second begins), so this is the walk's visiting order backwards
+  std::vector<int> leaves_emitted;
+  explicit LinkBuilder(const rt_scene_desc& sc) : s(sc), node_seen((size_t)std::max(0, sc.n_nodes), 0) {
+    links.reserve((size_t)std::max(0, sc.n_nodes) * 2 + 16);  // a node's entry and at most one leaf entry per child
+    leaves_emitted.reserve((size_t)std::max(0, sc.n_nodes) + 16);
+  }
 
   // Axis-aligned box around a box of holder `h`'s frame taken to world space (src/hittable.rs:166-197 for the rotation, 127-138
   // for the translation), with a margin that covers the rounding of these few operations many times over.
@@ -116,6 +122,7 @@ struct LinkBuilder {
     l.miss = next;
     l.depth = depth; l.tree = tree;
     links.push_back(l);
+    if (tree == 0) leaves_emitted.push_back(obj);
     return (int)links.size() - 1;
   }
   int child(int c, int next, int depth, int tree, int holder = -1) {
@@ -136,6 +143,9 @@ struct LinkBuilder {
     if (depth > 512) { err = "BVH deeper than 512 levels"; return LINK_END; }
     node_seen[n] = 1;
     const rt_bvh_node& nd = s.nodes[n];
+    // the children's records are read next (the second child's at once, the first child's after the second subtree)
+    if (nd.right >= 0 && nd.right < s.n_nodes) __builtin_prefetch(&s.nodes[nd.right]);
+    if (nd.left >= 0 && nd.left < s.n_nodes) __builtin_prefetch(&s.nodes[nd.left]);
     int me = (int)links.size();
     links.push_back(TmpLink{});
     int right_first, left_first;
@@ -390,26 +400,44 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
       if (order.size() != in.size()) order_err = "rt_upload_scene: internal error while ordering links";
     }
     if (!uniform || !order_err.empty()) {
-      // stable counting sort by (nested?, depth)
+      // stable counting sort by (nested?, depth), on the host's threads: every thread counts the keys of its chunk, the counts
+      // are turned into first positions chunk by chunk (so that equal keys keep their order), and every thread places its chunk
       order.resize(in.size());
+      const size_t n_chunks = parallel_chunk_count(in.size());
+      std::vector<int> chunk_max(n_chunks, 0);
+      parallel_chunks(in.size(), [&](size_t t, size_t lo, size_t hi) {
+        int m = 0;
+        for (size_t i = lo; i < hi; ++i) m = std::max(m, in[i].depth);
+        chunk_max[t] = m;
+      });
       int max_depth = 0;
-      for (const TmpLink& l : in) max_depth = std::max(max_depth, l.depth);
+      for (int m : chunk_max) max_depth = std::max(max_depth, m);
       const size_t n_keys = 2 * (size_t)(max_depth + 1);
       auto key = [&](const TmpLink& l) { return (size_t)(l.tree != 0) * (size_t)(max_depth + 1) + (size_t)l.depth; };
-      std::vector<size_t> first(n_keys + 1, 0);
-      for (const TmpLink& l : in) ++first[key(l) + 1];
-      for (size_t k = 0; k < n_keys; ++k) first[k + 1] += first[k];
-      for (size_t i = 0; i < in.size(); ++i) order[first[key(in[i])]++] = (int)i;
+      std::vector<std::vector<size_t>> count(n_chunks, std::vector<size_t>(n_keys, 0));
+      parallel_chunks(in.size(), [&](size_t t, size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) ++count[t][key(in[i])];
+      });
+      size_t at = 0;
+      for (size_t k = 0; k < n_keys; ++k)
+        for (size_t t = 0; t < n_chunks; ++t) { const size_t n_here = count[t][k]; count[t][k] = at; at += n_here; }
+      parallel_chunks(in.size(), [&](size_t t, size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) order[count[t][key(in[i])]++] = (int)i;
+      });
     }
     std::vector<int> new_index(order.size());
-    for (size_t i = 0; i < order.size(); ++i) new_index[order[i]] = (int)i;
+    parallel_chunks(order.size(), [&](size_t, size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i) new_index[order[i]] = (int)i;
+    });
     std::vector<TmpLink> out(order.size());
-    for (size_t i = 0; i < order.size(); ++i) {
-      TmpLink l = in[order[i]];
-      if (!(l.hit & LEAF_FLAG)) l.hit = (uint32_t)new_index[l.hit];
-      if (l.miss >= 0) l.miss = new_index[l.miss];
-      out[i] = l;
-    }
+    parallel_chunks(order.size(), [&](size_t, size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i) {
+        TmpLink l = in[order[i]];
+        if (!(l.hit & LEAF_FLAG)) l.hit = (uint32_t)new_index[l.hit];
+        if (l.miss >= 0) l.miss = new_index[l.miss];
+        out[i] = l;
+      }
+    });
     root_io = new_index[root_io];
     for (int& r : sub_root_io)
       if (r >= 0) r = new_index[r];
@@ -423,8 +451,10 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   // take the holder's wrappers and become leaves of the main tree.  A scene left without nested trees runs the kernels that carry
   // no nested-walk code (half the registers).  RTAMD_KEEP_NESTED=1 turns this off.
   const bool own_tree = !uniform && !std::getenv("RTAMD_REFERENCE_TREE");
-  std::vector<rt_object> objects32(s->objects, s->objects + s->n_objects);
-  std::vector<rt_shape> shapes32(s->shapes, s->shapes + s->n_shapes);
+  // (copies of the caller's arrays only where something in them changes: scenes with nested trees)
+  std::vector<rt_object> objects32;
+  std::vector<rt_shape> shapes32;
+  if (has_nested) { objects32.assign(s->objects, s->objects + s->n_objects); shapes32.assign(s->shapes, s->shapes + s->n_shapes); }
   std::vector<char> dissolved((size_t)s->n_objects, 0);
   int preset32 = preset;
   if (own_tree) {
@@ -483,7 +513,8 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   // leaves to the ones a ray gets to test (see BoxLink).  The image then has no nested tree and runs the kernels without
   // nested-walk code, whose lanes step through the tree instead of each finishing its own walk inside a turn (final-scene: 10
   // of 64 lanes were active there).  RTAMD_KEEP_NESTED=1 turns this off as well.
-  std::vector<rt_object> objects64(s->objects, s->objects + s->n_objects);
+  std::vector<rt_object> objects64;
+  if (has_nested) objects64.assign(s->objects, s->objects + s->n_objects);
   std::vector<char> splice((size_t)s->n_objects, 0);
   bool nested_left64 = false, spliced_any = false;
   if (!uniform && has_nested) {
@@ -519,19 +550,17 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   // texture reads (u, v): with one on such an object the copies stay.
   const bool stale_uv_read = reads_leftover_uv(*s);
   if (!uniform && !stale_uv_read && !std::getenv("RTAMD_KEEP_COPIES")) {
+    mark("features, preset");
     FastTreeBuilder sig(*s);
-    std::vector<int> order;
-    for (int k = root; k >= 0;) {
-      const TmpLink& l = lb.links[(size_t)k];
-      if (l.hit & LEAF_FLAG) { order.push_back((int)(l.hit & LEAF_INDEX_MASK)); k = l.miss; }
-      else k = (int)l.hit;
-    }
+    sig.sort_pairs = [&](uint64_t* k, uint32_t* v, size_t n) { return gpu_sort_pairs(c, k, v, n) == RT_OK; };
+    // leaves of the world's tree in the order the walk visits them
+    const std::vector<int> order(lb.leaves_emitted.rbegin(), lb.leaves_emitted.rend());
     skip = sig.earlier_copies(order, [&](int o) { return sig.copy_eligible(o); });
     for (char f : skip) skipped_any = skipped_any || f != 0;
     mark("f64 list: copies found");
   }
   rt_scene_desc scene64 = *s;
-  scene64.objects = objects64.data();
+  if (has_nested) scene64.objects = objects64.data();
   std::vector<TmpLink> links64;
   int root64 = LINK_END;
   std::vector<int> sub_root64((size_t)s->n_objects, LINK_END);
@@ -546,7 +575,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     std::vector<uint64_t> keys;
     keys.reserve((size_t)s->n_objects);
     for (int i = 0; i < s->n_objects; ++i) {
-      const rt_object& o = objects64[(size_t)i];
+      const rt_object& o = scene64.objects[i];
       if ((o.flags & (RT_OBJ_SUB_BVH | RT_OBJ_MEDIUM)) || skip[(size_t)i]) continue;
       const rt_shape& sh = s->shapes[o.geom];
       uint64_t h = 0xCBF29CE484222325ull ^ (uint64_t)(uint32_t)sh.tag ^ ((uint64_t)o.flags << 8);
@@ -561,7 +590,9 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
       if (o.flags & RT_OBJ_ROTATE_Y) { mix(o.sin_theta); mix(o.cos_theta); }
       keys.push_back(h);
     }
-    std::sort(keys.begin(), keys.end());
+    std::vector<uint32_t> unused_vals;
+    if (keys.size() >= 65536) unused_vals.resize(keys.size());
+    if (unused_vals.empty() || gpu_sort_pairs(c, keys.data(), unused_vals.data(), keys.size()) != RT_OK) std::sort(keys.begin(), keys.end());
     coincident = std::adjacent_find(keys.begin(), keys.end()) != keys.end();
     if (coincident && timing) std::fprintf(stderr, "rt_upload_scene: double precision keeps the list walk of the caller's tree (coincident objects)\n");
   }
@@ -579,14 +610,123 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     mark("f64 list: nested trees spliced, copies left out");
   }
   rt_scene_desc scene32 = *s;
-  scene32.objects = objects32.data();
-  scene32.shapes = shapes32.data();
-  scene32.n_shapes = (int32_t)shapes32.size();
+  if (has_nested) {
+    scene32.objects = objects32.data();
+    scene32.shapes = shapes32.data();
+    scene32.n_shapes = (int32_t)shapes32.size();
+  }
   mark("preset, nested trees");
   // the own tree's four-wide form, handed to the images that walk the own tree when its walk's stack fits (device_scene.h: kWideStack)
   std::vector<WideTmp> wide_nodes;
   std::vector<uint32_t> wide_pre;  // leaves that image keeps outside the tree (FastTreeBuilder::wide_pre)
-  if (own_tree) {
+  // Scenes of 100 000 objects and more (RTAMD_GPU_BUILD_MIN sets another threshold) whose objects are all plain leaves - no nested
+  // tree, no medium, no sphere of negative radius - get that tree from the device-side builder (gpu_build.hip): the host computes
+  // one box and one leaf word per object on its threads and the rest happens on the GPU.  Such an image carries no threaded list of
+  // the own tree (nothing walks it when the four-wide form exists); if the four-wide walk would need a deeper stack than the
+  // kernels have, the host builder below takes over.
+  struct DeviceTree {
+    WideNode* nodes = nullptr;
+    uint32_t n = 0;
+    ~DeviceTree() { if (nodes) (void)hipFree(nodes); }
+  } device_tree;
+  size_t gpu_min = 100000;
+  if (const char* e = std::getenv("RTAMD_GPU_BUILD_MIN")) gpu_min = (size_t)std::max(2, atoi(e));
+  if (own_tree && !has_nested && !(feat & F_MEDIUM) && !inverted_box && (size_t)s->n_objects >= gpu_min && !std::getenv("RTAMD_NO_GPU_BUILD") &&
+      !std::getenv("RTAMD_NO_WIDE")) {
+    FastTreeBuilder ftb(scene32);
+    std::vector<int> keep;
+    keep.reserve((size_t)s->n_objects);
+    for (int o = 0; o < s->n_objects; ++o)
+      if (!skip[(size_t)o]) keep.push_back(o);
+    const size_t n_keep = keep.size();
+    std::vector<float> boxes(6 * n_keep);
+    std::vector<uint32_t> words(n_keep);
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char* e = std::getenv("OMP_NUM_THREADS")) hw = std::min<unsigned>(hw ? hw : 1u, (unsigned)std::max(1, atoi(e)));
+    const size_t n_threads = n_keep < 65536 ? 1 : std::max(1u, std::min(hw, 16u));
+    std::vector<Box3d> whole_of(n_threads), centres_of(n_threads);
+    auto work = [&](size_t t, size_t lo, size_t hi) {
+      Box3d whole, cen;
+      whole.reset(); cen.reset();
+      for (size_t q = lo; q < hi; ++q) {
+        const Box3d b = ftb.leaf_box(keep[q]);
+        for (int k = 0; k < 3; ++k) {
+          float f = (float)b.mn[k];
+          boxes[6 * q + k] = ((double)f > b.mn[k]) ? std::nextafterf(f, -INFINITY) : f;  // single-precision boxes contain the double ones
+          f = (float)b.mx[k];
+          boxes[6 * q + 3 + k] = ((double)f < b.mx[k]) ? std::nextafterf(f, INFINITY) : f;
+        }
+        words[q] = ftb.word_of(keep[q]);
+        whole.grow(b);
+        Box3d c1;
+        for (int k = 0; k < 3; ++k) c1.mn[k] = c1.mx[k] = 0.5 * (b.mn[k] + b.mx[k]);
+        cen.grow(c1);
+      }
+      whole_of[t] = whole; centres_of[t] = cen;
+    };
+    {
+      std::vector<std::thread> pool;
+      const size_t per = (n_keep + n_threads - 1) / n_threads;
+      for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work, t, std::min(n_keep, t * per), std::min(n_keep, (t + 1) * per));
+      work(0, 0, std::min(n_keep, per));
+      for (std::thread& t : pool) t.join();
+    }
+    Box3d whole;
+    whole.reset();
+    for (const Box3d& b : whole_of) whole.grow(b);
+    // objects as large as the scene stay outside the tree, tested ahead of the walk (FastTreeBuilder::wide_pre has the reason)
+    std::vector<uint32_t> pre;
+    std::vector<char> is_pre(n_keep, 0);
+    if (!std::getenv("RTAMD_NO_PRE_LEAVES")) {
+      const double whole_area = whole.area();
+      for (size_t q = 0; q < n_keep && pre.size() < kWidePre; ++q) {
+        Box3d b;
+        for (int k = 0; k < 3; ++k) { b.mn[k] = boxes[6 * q + k]; b.mx[k] = boxes[6 * q + 3 + k]; }
+        if (b.area() >= 0.5 * whole_area) { pre.push_back(words[q]); is_pre[q] = 1; }
+      }
+    }
+    Box3d cen;
+    cen.reset();
+    if (pre.empty()) {
+      for (const Box3d& b : centres_of) cen.grow(b);
+    } else {  // compact the leaves that stay, and take the bounds of their centres
+      size_t w = 0;
+      for (size_t q = 0; q < n_keep; ++q) {
+        if (is_pre[q]) continue;
+        for (int k = 0; k < 6; ++k) boxes[6 * w + k] = boxes[6 * q + k];
+        words[w] = words[q];
+        Box3d c1;
+        for (int k = 0; k < 3; ++k) c1.mn[k] = c1.mx[k] = 0.5 * ((double)boxes[6 * w + k] + (double)boxes[6 * w + 3 + k]);
+        cen.grow(c1);
+        ++w;
+      }
+      boxes.resize(6 * w); words.resize(w);
+    }
+    mark("own tree: boxes (host threads)");
+    if (words.size() >= 2) {
+      int need = 0;
+      int brc = gpu_build_wide(c, boxes.data(), words.data(), words.size(), cen.mn, cen.mx, &device_tree.nodes, &device_tree.n, &need);
+      if (brc != RT_OK) return brc;
+      if (timing) std::fprintf(stderr, "rt_upload_scene: device-built four-wide tree of %u nodes, stack need %d (limit %u)\n", device_tree.n, need, kWideStack);
+      if (need > (int)kWideStack) {  // the host builder's tree is shallower
+        (void)hipFree(device_tree.nodes);
+        device_tree.nodes = nullptr; device_tree.n = 0;
+      } else {
+        wide_pre = pre;
+        // a list of one box and one leaf stands where the own tree's list would be
+        TmpLink b{};
+        for (int k = 0; k < 3; ++k) { b.bmin[k] = whole.mn[k]; b.bmax[k] = whole.mx[k]; }
+        b.hit = 1u; b.miss = LINK_END; b.depth = 0; b.tree = 0;
+        TmpLink l{};
+        l.hit = words[0]; l.miss = LINK_END; l.depth = 1; l.tree = 0;
+        fast_links = {b, l};
+        fast_root = 0;
+        fast_sub_root.assign((size_t)s->n_objects, LINK_END);
+      }
+      mark("own tree: built on the device");
+    }
+  }
+  if (own_tree && !device_tree.nodes) {
     FastTreeBuilder ftb(scene32);
     ftb.build(lb.links, root, sub_root, dissolved, fast_links, fast_root, fast_sub_root);
     if (!ftb.wide.empty() && ftb.wide_stack_need <= (int)kWideStack) { wide_nodes.swap(ftb.wide); wide_pre.swap(ftb.wide_pre); }
@@ -620,7 +760,8 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
   // two leaves tie and have those traced by the list walk of the caller's tree, which the image carries too (F_EXACT, kernels.h).
   // Kept on the list walk: scenes in which a texture reads a leftover (u, v) (the leftover depends on the order of the tests),
   // scenes with coincident objects (every ray on them would tie), and RTAMD_F64_LIST=1.
-  const bool exact_own = own_tree && !wide_nodes.empty() && !stale_uv_read && !coincident && !nested_left64 && !std::getenv("RTAMD_F64_LIST");
+  const bool have_wide_tree = !wide_nodes.empty() || device_tree.nodes != nullptr;
+  const bool exact_own = own_tree && have_wide_tree && !stale_uv_read && !coincident && !nested_left64 && !std::getenv("RTAMD_F64_LIST");
   // RT_F64_OWN_TREE: the library's tree in double with its own cheaper leaf forms (boxes as slabs, re-centred spheres), compared with
   // the reference by tolerance; for sphere scenes that is the default image itself
   const bool want_own64 = own_tree && preset32 != PRESET_BALLS_LDS && !std::getenv("RTAMD_NO_F64_OWN_TREE");
@@ -631,17 +772,18 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     if (hipSetDevice(device) != hipSuccess) { rc_sd = RT_E_HIP; err_sd = "hipSetDevice failed"; return; }
     const std::vector<WideTmp>* w = exact_own ? &wide_nodes : nullptr;
     const std::vector<uint32_t>* p = exact_own ? &wide_pre : nullptr;
-    rc_sd = relinked ? build_image<double>(c, scene64, links64, root64, sub_root64, preset64, c->sd, w, p, exact_own)
-                     : build_image<double>(c, *s, links, root, sub_root, preset, c->sd, w, p, exact_own);
+    const WideNode* dw = exact_own ? device_tree.nodes : nullptr;
+    rc_sd = relinked ? build_image<double>(c, scene64, links64, root64, sub_root64, preset64, c->sd, w, p, exact_own, dw, device_tree.n)
+                     : build_image<double>(c, *s, links, root, sub_root, preset, c->sd, w, p, exact_own, dw, device_tree.n);
     if (rc_sd != RT_OK) err_sd = g_err;
   });
   std::thread t_own([&] {
     if (!want_own64) return;
     if (hipSetDevice(device) != hipSuccess) { rc_own = RT_E_HIP; err_own = "hipSetDevice failed"; return; }
-    rc_own = build_image<double>(c, scene32, fast_links, fast_root, fast_sub_root, preset32, c->sd_own, &wide_nodes, &wide_pre, false);
+    rc_own = build_image<double>(c, scene32, fast_links, fast_root, fast_sub_root, preset32, c->sd_own, &wide_nodes, &wide_pre, false, device_tree.nodes, device_tree.n);
     if (rc_own != RT_OK) err_own = g_err;
   });
-  rc = own_tree ? build_image<float>(c, scene32, fast_links, fast_root, fast_sub_root, preset32, c->sf, &wide_nodes, &wide_pre, false)
+  rc = own_tree ? build_image<float>(c, scene32, fast_links, fast_root, fast_sub_root, preset32, c->sf, &wide_nodes, &wide_pre, false, device_tree.nodes, device_tree.n)
                 : build_image<float>(c, *s, links, root, sub_root, preset, c->sf, nullptr, nullptr, false);
   t_sd.join();
   t_own.join();
