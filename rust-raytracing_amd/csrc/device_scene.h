@@ -215,7 +215,11 @@ template <uint32_t FEATURES, int WALK> struct Cfg {
   // by an ulp or two (reciprocal multiply, refined hardware estimates).  Their scenes have no clusters of small specular spheres
   // that would amplify the difference, so paths still follow the reference arithmetic's to ~1e-13; the per-lane presets, whose
   // scenes do have such clusters, keep the IEEE forms everywhere.
+#ifdef RT_STRICT_F64  // measurement build: true quotients and square roots everywhere (with -ffp-contract=off: the reference's plain IEEE arithmetic)
+  static constexpr bool relaxed() { return false; }
+#else
   static constexpr bool relaxed() { return WALK == 0; }
+#endif
   // Per-lane walks that step through the tree (k_paths_stepwise, traverse_wide): keep the winning candidate as (t, leaf, side) and
   // build the record once, after the walk, where a record per accepted candidate is costly - boxes (six rectangle records),
   // wrappers, media (two boundary records per test); final-scene +17 % in single precision.  Sphere-only presets fill the record
