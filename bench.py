@@ -419,7 +419,7 @@ def main():
                     "rgb8_max_abs_diff": int(d8.max()), "rgb8_frac_bytes_differing": float((d8 > 0).mean()),
                     "rays_rel_diff": abs(own["rays_all"] - head["rays_all"]) / head["rays_all"]},
                 "note": "RT_PRECISION_F64 | RT_F64_OWN_TREE: the library's tree with its cheaper leaf forms (a box as three slabs, spheres of a "
-                        "dissolved nested tree re-centred) and without the second tracing of rays that meet an exact tie",
+                        "dissolved nested tree re-centred) and without the second tracing of rays that meet an exact tie (rt_stats.rays_retraced)",
             }
         if side is not None:
             if True:

@@ -36,14 +36,17 @@ extern "C" {
 #define RT_E_NO_SCENE 4     /* render/trace before rt_upload_scene */
 #define RT_E_UNSUPPORTED 5  /* scene uses a composition the device code does not implement */
 
-/* Arithmetic type of the device kernels.  The reference computes in f64. */
+/* Arithmetic type of the device kernels.  The reference computes in f64.
+ * RT_PRECISION_F64 reports what the reference's own walk reports.  The closest hit does not depend on the tree that is walked
+ * unless two different surfaces lie at exactly the same distance, so on scenes too large for the small-scene kernels the library
+ * walks a tree of its own with the reference's leaf arithmetic, notes the rays on which two leaves tie, and traces the paths of
+ * such a ray a second time by the list walk of the caller's tree, in the reference's order (rt_stats.rays_retraced). */
 #define RT_PRECISION_F32 0
 #define RT_PRECISION_F64 1
-/* RT_PRECISION_F64 | RT_F64_OWN_TREE: double-precision arithmetic on the tree the library builds for itself (the one the F32
- * kernels walk) instead of the tree the caller uploaded.  The closest hit does not depend on the tree, so images agree to
- * rounding; what is given up is the reference's rule for exactly coincident surfaces (the last one its walk tests wins), which
- * only the caller's tree can reproduce.  Several times faster on large scenes (the reference's random-axis tree tests 105 boxes
- * per ray on a million spheres, the library's 47).  Scenes that take a small-scene preset have no such tree: the flag is ignored. */
+/* RT_PRECISION_F64 | RT_F64_OWN_TREE: the same walk with cheaper leaf forms (a box as three slabs instead of six rectangles,
+ * spheres of a dissolved nested tree re-centred) and without the second pass.  Images agree to rounding; what is given up is the
+ * reference's rule for exactly coincident surfaces (the last one its walk tests wins).  Scenes that take a small-scene preset
+ * have no such tree: the flag is ignored. */
 #define RT_F64_OWN_TREE 0x400
 
 /* Pipeline.  FUSED = per-bounce ray queues, one trace+shade kernel per bounce;
@@ -197,8 +200,9 @@ typedef struct rt_stats {
   uint32_t scene_in_lds;       /* kernel preset the scene selected: 0 boxes, 1 smoke, 2 spheres, 3 all (scene in LDS), 4 all (top links in LDS), 5/6 spheres-only lane walk (LDS / top links), 7/8 all without nested trees (images whose nested trees were dissolved or spliced), 9/10 spheres-only / all without nested trees on the four-wide form of the library's own tree, 11/12 the same with the reference's leaf arithmetic and tie rule (the double-precision default) */
   uint32_t kernel_variant;     /* PERSISTENT pipeline: which instantiation of the path kernel ran, RT_VARIANT_* bits */
   uint32_t pad;
-  uint64_t paths_redone;       /* double precision on the library's own tree: paths on which two different surfaces lay at exactly the
-                                  same distance, traced a second time by the list walk in the reference's order (src/bvh.rs:108-119) */
+  uint64_t rays_retraced;      /* double precision on the library's own tree: closest-hit queries on which two different surfaces lay at
+                                  exactly the same distance, answered a second time by the list walk in the reference's order
+                                  (src/bvh.rs:108-119) */
 } rt_stats;
 #define RT_VARIANT_FIXED_GRAB 1u       /* paths handed out in constant grabs of 2048 per wave (large frames) */
 #define RT_VARIANT_CHUNKED 2u          /* a lane sums up to 16 samples of one pixel before its one atomic add (cheap bright paths) */

@@ -37,7 +37,6 @@ constexpr uint64_t kTargetPathsPerPass = 64ull << 20;
 constexpr uint32_t kMaxDepth = 4096;
 constexpr uint32_t kRayCountWords = 16 + 8 * 4 * 4096;  // ray counter, then 8 diagnostic words per wave of up to 4096 workgroups
 using rtd::kFlatMaxLeaves;  // scenes with at most this many leaves take the small-scene presets: every leaf tested, in tree order, no box tests
-constexpr uint32_t kRedoCapacity = 1u << 18;  // paths per launch that may be handed to k_redo_paths (two words each: 2 MiB, allocated once per context)
 constexpr uint32_t kSegments = 64;  // queue segments (a multiple of the 8 XCDs; at most the workgroup size)
 constexpr uint32_t kCounterWords = (kMaxDepth + 2) * kSegments * 11;  // per bounce and segment: queue count, 2 chunk cursors, 8 class counts
 
@@ -124,7 +123,6 @@ struct rt_context {
   size_t ws_bytes = 0;
   uint32_t* d_counters = nullptr;  // [kCounterWords]
   unsigned long long* d_ray_count = nullptr;
-  uint32_t* d_redo = nullptr;  // [2 * kRedoCapacity]: (pixel, sample) of the paths a launch gave up at a tie (kernels.h: k_redo_paths)
   void* accum = nullptr;
   size_t accum_bytes = 0;
   uint8_t* d_rgb = nullptr;  // rt_resolve: the RGB8 image on the device, before its copy to the host

@@ -3,17 +3,20 @@
 // the library is free to build another).  Input: one box and one leaf word per object.  Steps, all on the context's stream:
 //   1. 63-bit Morton codes of the box centres (21 bits an axis, one scale for all axes so that cells are cubes),
 //   2. a radix sort of (code, leaf) pairs (rocPRIM's device-wide sort through hipCUB),
-//   3. the four-wide tree top-down over the sorted order, one launch per level: a node owns a run of leaves and cuts it in four.
-//      Each cut is sought near a quartile of the run - within 1/32 of the run's length on either side - at the place where the
-//      Morton codes change in their most significant bit, i.e. on the largest cell boundary the window holds; runs of four
-//      leaves or fewer end the descent.  The windows bound the imbalance (a child holds between 3/16 and 5/16 of its parent),
-//      so the tree of a million leaves is at most twelve levels deep and the walk's stack (three entries a level) fits the
-//      kernels' 36; should a tree still come out deeper, it is cut again at the exact quartiles,
-//   4. boxes bottom-up, one launch per level, and with them the stack the deepest walk can need.
+//   3. the four-wide tree top-down over the sorted order, one launch pair per level: a node owns a run of leaves and cuts it into
+//      up to four parts.  Runs of up to 128 leaves are cut by the surface-area heuristic over the cuts the sorted order offers
+//      (in two, then twice more the part of largest area: the host builder's rule, accel_build.h); longer runs near their
+//      quartiles - within 1/9 (runs up to 4096) or 1/32 of the run's length on either side - at the place where the Morton
+//      codes change in their most significant bit, i.e. on the largest cell boundary the window holds; runs of four leaves or
+//      fewer end the descent.  Parts that hold two leaves or more become nodes, numbered by a prefix sum over the level, so the
+//      nodes come out level by level in the order of their parents and the tree is the same on every run,
+//   4. boxes bottom-up, one launch per level, and with them the stack the deepest walk can need.  The windows bound the
+//      imbalance, so the tree of a million leaves is twelve levels deep and the walk's stack (three entries a level) fits the
+//      kernels' 36; should a tree come out deeper, it is cut again with the narrow windows only, then at the exact quartiles.
 // A plain radix tree over the codes (one inner node per differing bit) is the usual form of this builder; its height follows
 // the codes - forty levels on the million-sphere field, neighbours a tenth of a unit apart - and with it the walk's worst-case
 // stack, which is why the cuts here are tied to the quartiles instead.
-// Twenty-odd small launches and one 4-byte read-back per level; a million spheres take a few milliseconds.
+// Forty-odd small launches and one 4-byte read-back per level; a million spheres take 6 ms.
 #include <hipcub/hipcub.hpp>
 
 #include "context.h"

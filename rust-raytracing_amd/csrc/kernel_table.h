@@ -14,9 +14,6 @@ template <class R> struct KernelTable {
   // returns which instantiation it launched: RT_VARIANT_* bits (rtamd.h: rt_stats.kernel_variant)
   uint32_t (*paths_persistent)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, unsigned long long total_paths,
                                unsigned long long* path_cursor, unsigned long long* ray_count, R* accum);
-  // F_EXACT presets: traces the paths of fp.redo_list again with the list walk (k_redo_paths); nothing for the other presets
-  void (*redo_paths)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, uint32_t n, unsigned long long* ray_count,
-                     R* accum);
   int (*resident_blocks_per_cu)(int kernel, uint32_t lds);  // kernel: 0 bounce_fused, 1 trace, 2 shade, 3 paths_persistent
   void (*trace)(uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, PathQueue<R> in, HitQueue<R> hits,
                 uint32_t* counters, uint32_t* cursors, unsigned long long* ray_count, uint32_t* class_counters, uint32_t* class_index, uint32_t capacity, R* accum,
@@ -81,11 +78,6 @@ template <class R, class C> KernelTable<R> make_table() {
       else hipLaunchKernelGGL((k_paths_stepwise<R, C, false>), dim3(grid), dim3(kStepThreads), lds, st, sc, fp, total_paths, path_cursor, ray_count, accum);
       return vf | RT_VARIANT_STEPWISE;
     }
-  };
-  t.redo_paths = [](uint32_t grid, uint32_t lds, hipStream_t st, const DeviceScene<R>& sc, const FrameParams& fp, uint32_t n, unsigned long long* ray_count,
-                    R* accum) {
-    if constexpr (C::has(F_EXACT) && sizeof(R) == sizeof(double))
-      hipLaunchKernelGGL((k_redo_paths<R, C>), dim3(grid), dim3(kBlockThreads), lds, st, sc, fp, n, ray_count, accum);
   };
   t.resident_blocks_per_cu = [](int kernel, uint32_t lds) {
     int n = 0;

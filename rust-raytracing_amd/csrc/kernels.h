@@ -129,10 +129,6 @@ struct FrameParams {
   // u % n_pixels).  `n_samples` = samples of this launch.  Frames whose paths are short and all bright (a textured globe in
   // front of a sky) otherwise spend two thirds of their time in the radiance atomics.
   uint32_t chunk, n_samples;
-  // F_EXACT kernels: (pixel, sample) of the paths that met a tie (see traverse_wide) and were given up, to be traced again by
-  // k_redo_paths; `redo_cap` entries of two words, the number of entries asked for in word 1 of the ray counter block.
-  uint32_t* redo_list;
-  uint32_t redo_cap;
   // Row bands (rt_render_params::band_*): band_stride > 1 means that the launch renders only the rows of the bands b with
   // b % band_stride == band_offset, bands being 1 << band_shift rows; n_pixels then counts the pixels of those rows and the feeder
   // numbers them row after row ("local" rows), while `height` stays the frame's.
@@ -551,7 +547,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
   // F_EXACT: two different leaves at exactly the same distance - the order of the tests would decide (see traverse_wide)
   constexpr bool EXACT = WIDE && C::has(F_EXACT) && sizeof(R) == sizeof(double);
   bool tie = false;
-  unsigned long long redone_rays = 0;  // per lane: rays of the paths this lane gave up
+  unsigned long long retraced = 0;  // per lane: rays answered a second time by the list walk
   auto step_leaf = [&](uint32_t word, Stream& media) {
     if constexpr (DEFER) {
       RayInv<R> ri(st.ray.d);
@@ -579,19 +575,17 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
     if ((uint32_t)__popcll(idle) >= (WIDE ? kRestartLanesWide : kRestartLanes) || idle == ~0ull) {
       bool to_scatter = false;
       if constexpr (EXACT) {
-        // A walk that met a tie: the path is given up here - nothing of it has reached the sums yet (only a path's last vertex
-        // adds radiance) - and goes on the list of paths that k_redo_paths traces again with the list walk.  Its rays so far
-        // leave the count; the second tracing counts them.  A full list leaves the path with what the walk reported.
+        // A walk that met a tie - two different leaves at exactly the same distance - answers nothing by itself: which of the two
+        // the reference reports hangs on the order of its walk and on its boxes (src/bvh.rs:108-119, src/aabb.rs:40).  The lane
+        // traces the ray once more, by the list walk of the caller's tree in the reference's order, while the other lanes of the
+        // wave wait: a few thousand rays of a frame's half billion (final-scene: rays that slip between two ground blocks), a
+        // fraction of a percent of the waves' time.  Word 1 of the counter block counts them.
         if (i < 0 && active && tie) {
-          const uint32_t slot = atomicAdd(reinterpret_cast<uint32_t*>(ray_count + 1), 1u);
-          if (slot < fp.redo_cap) {
-            fp.redo_list[2u * slot] = st.pixel;
-            fp.redo_list[2u * slot + 1u] = st.sample;
-            redone_rays += (unsigned long long)(bounce + 1u);
-            active = false;
-            best_leaf = -1;
-            resume = 0u;
-          }
+          Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
+          rec = Rec<R>();
+          any = traverse_lane<R, C, 0>(sv, sc.root_link, st.ray, (R)0.001, Lim<R>::inf(), rec, media, st.org, 0u, nullptr);
+          best_leaf = -1;
+          ++retraced;
         }
         if (i < 0) tie = false;
       }
@@ -716,7 +710,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
   RT_STAMP_FLUSH(ray_count);
   if (lane == 0u && n_rays != 0ull) atomicAdd(ray_count, n_rays);
   if constexpr (EXACT) {
-    if (redone_rays != 0ull) atomicAdd(ray_count, 0ull - redone_rays);  // modulo 2^64: a subtraction
+    if (retraced != 0ull) atomicAdd(ray_count + 1, retraced);
   }
 }
 
@@ -958,43 +952,6 @@ __global__ __launch_bounds__(256) void k_sample_radiance(DeviceScene<R> sc, uint
     out[(size_t)i * 4u + 1] = (double)sum.y;
     out[(size_t)i * 4u + 2] = (double)sum.z;
     out[(size_t)i * 4u + 3] = (double)n_rays;
-  }
-}
-
-// F_EXACT: the paths k_paths_stepwise gave up at a tie (FrameParams::redo_list), traced again from their primary ray, one thread
-// each: every ray by the four-wide walk and, where that meets the tie, by the list walk, which keeps the reference's order of tests
-// (src/bvh.rs:108-119) and with it the reference's answer among surfaces at exactly the same distance (closest_hit).  A few
-// hundred paths per frame at most.
-template <class R, class C>
-__global__ __launch_bounds__(256) void k_redo_paths(DeviceScene<R> sc, FrameParams fp, uint32_t n, unsigned long long* ray_count, R* accum) {
-  extern __shared__ __align__(16) uint8_t lds[];
-  const SceneView<R, C> sv = make_view<R, C>(sc, lds);
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const uint32_t px = fp.redo_list[2u * i], sm = fp.redo_list[2u * i + 1u];
-    Ray<R> ray = primary_ray<R, C::relaxed()>(sc.camera, fp.width, fp.height, px, sm, fp.seed);
-    V3<R> thr((R)1, (R)1, (R)1);
-    unsigned long long n_rays = 0;
-    Origin org;
-    for (uint32_t bounce = 0; bounce < fp.max_depth; ++bounce) {
-      ++n_rays;
-      Stream media(fp.seed, px, sm, bounce, STAGE_MEDIA);
-      Rec<R> rec;
-      if (!closest_hit<R, C>(sv, sc.root_link, ray, (R)0.001, Lim<R>::inf(), rec, media, org)) {
-        add_radiance(accum, px, thr * background_color<R, C>(sc.background, ray.d));
-        break;
-      }
-      Stream rng(fp.seed, px, sm, bounce, STAGE_SCATTER);
-      V3<R> emitted, attenuation;
-      Ray<R> scattered;
-      const bool alive = shade_hit<R, C>(sv, ray, rec, rng, emitted, attenuation, scattered);
-      add_radiance(accum, px, thr * emitted);
-      if (!alive) break;
-      thr = thr * attenuation;
-      ray = scattered;
-      org = Origin(rec.leaf, rec.side);
-    }
-    atomicAdd(ray_count, n_rays);
   }
 }
 

@@ -383,8 +383,6 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
     if (const char* e = getenv("RTAMD_CHUNK")) chunk = im.preset == PRESET_SPHERES ? (uint32_t)std::max(1, atoi(e)) : 1u;  // measurement switch
     fp.chunk = chunk;
     fp.n_samples = n_samples;
-    fp.redo_list = c->d_redo;
-    fp.redo_cap = kRedoCapacity;
     fp.band_shift = band_shift; fp.band_stride = banded ? p.band_stride : 0u; fp.band_offset = banded ? p.band_offset : 0u;
     const unsigned long long total_paths = (unsigned long long)n_pixels * ((n_samples + chunk - 1) / chunk);  // units the path cursor counts
 #ifdef RT_STAMPS
@@ -412,25 +410,10 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     HIP_TRY(hipGetLastError());
     unsigned long long rays_stack[2] = {0, 0};
-    unsigned long long* const rays_dst = host_rays ? host_rays : rays_stack;  // word 0 rays, word 1 paths given up at a tie
+    unsigned long long* const rays_dst = host_rays ? host_rays : rays_stack;  // word 0 rays, word 1 rays traced a second time at a tie
     HIP_TRY(hipMemcpyAsync(rays_dst, cnt, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    uint64_t redone = 0;
-    if (rays_dst[1] != 0ull) {
-      // Paths on which two different surfaces lay at exactly the same distance (a handful, if any): traced again by the list walk in
-      // the reference's order.  Requests beyond the list's capacity stayed with what the four-wide walk reported.
-      redone = std::min<uint64_t>(rays_dst[1], kRedoCapacity);
-      if (const char* e = getenv("RTAMD_DUMP_REDO")) {  // diagnostic: the first (pixel, sample) pairs of the list, on stderr
-        std::vector<uint32_t> head(2 * std::min<uint64_t>(redone, (uint64_t)std::max(1, atoi(e))));
-        HIP_TRY(hipMemcpy(head.data(), c->d_redo, head.size() * 4, hipMemcpyDeviceToHost));
-        for (size_t k = 0; k + 1 < head.size(); k += 2) fprintf(stderr, "redo %u %u\n", head[k], head[k + 1]);
-      }
-      const uint32_t redo_grid = (uint32_t)std::min<uint64_t>((redone + kBlock - 1) / kBlock, (uint64_t)c->n_cus * 4u);
-      im.table.redo_paths(redo_grid, im.lds_bytes, c->stream, im.dev, fp, (uint32_t)redone, cnt, accum);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemcpyAsync(rays_dst, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(hipStreamSynchronize(c->stream));
-    }
+    const uint64_t retraced = rays_dst[1];  // rays on which two leaves tied, answered by the list walk in the reference's order
     const unsigned long long rays = rays_dst[0];
 #ifdef RT_STAMPS
     {
@@ -464,7 +447,7 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
       stats->lds_bytes = im.lds_bytes;
       stats->scene_in_lds = (uint32_t)im.preset;
       stats->kernel_variant = variant | (im.device_built_tree ? RT_VARIANT_DEVICE_TREE : 0u);
-      stats->paths_redone = redone;
+      stats->rays_retraced = retraced;
     }
     return RT_OK;
   }

@@ -285,7 +285,6 @@ int rt_create(rt_context** out, int device) {
     if (hipEventCreate(&ev) != hipSuccess) return cleanup(RT_E_HIP, "hipEventCreate failed");
   if (hipMalloc((void**)&c->d_counters, sizeof(uint32_t) * kCounterWords) != hipSuccess) return cleanup(RT_E_HIP, "hipMalloc counters failed");
   if (hipMalloc((void**)&c->d_ray_count, sizeof(unsigned long long) * rti::kRayCountWords) != hipSuccess) return cleanup(RT_E_HIP, "hipMalloc ray counter failed");
-  if (hipMalloc((void**)&c->d_redo, sizeof(uint32_t) * 2u * rti::kRedoCapacity) != hipSuccess) return cleanup(RT_E_HIP, "hipMalloc redo list failed");
   if (hipHostMalloc((void**)&c->h_rays, 64, hipHostMallocDefault) != hipSuccess) return cleanup(RT_E_HIP, "hipHostMalloc failed");
   // set-up of the allocation-free entry point: this device's address of the static scratch array, looked up with the device current
   if (int rc = scratch_for_device(device, &c->scratch)) { std::string m = g_err; return cleanup(rc, m); }
@@ -304,7 +303,6 @@ void rt_destroy(rt_context* c) {
   if (c->d_rgb) (void)hipFree(c->d_rgb);
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->d_ray_count) (void)hipFree(c->d_ray_count);
-  if (c->d_redo) (void)hipFree(c->d_redo);
   if (c->h_rays) (void)hipHostFree(c->h_rays);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);

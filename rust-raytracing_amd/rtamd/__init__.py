@@ -62,7 +62,7 @@ class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("camera_rays", C.c_uint64), ("seconds", C.c_double), ("bounce_kernel_ms", C.c_double),
                 ("bounce_kernel_launches", C.c_uint64), ("gen_kernel_ms", C.c_double), ("passes", C.c_uint64),
                 ("lds_bytes", C.c_uint32), ("scene_in_lds", C.c_uint32), ("kernel_variant", C.c_uint32), ("pad", C.c_uint32),
-                ("paths_redone", C.c_uint64)]
+                ("rays_retraced", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -9,7 +9,7 @@ caller's tree in the reference's order.  Checked here:
   * rays constructed to hit, in exact arithmetic, the common edge of two ground blocks of equal height (a four-way tie among two
     top faces and two side faces): the default image and the list walk (RTAMD_F64_LIST) report the same object, side and record;
   * a render in which two overlapping coplanar rectangles of different materials face the camera, so that thousands of camera
-    rays tie: paths are handed to the second pass (rt_stats.paths_redone > 0) and the frame equals the list walk's frame.
+    rays tie: the rays are traced again by the list walk (rt_stats.rays_retraced > 0) and the frame equals the list walk's frame.
 """
 import numpy as np
 import pytest
@@ -106,13 +106,13 @@ def test_render_with_coplanar_overlapping_rectangles(gpu, rtamd, oracle, earth_r
         ed.objects["flags"][k] = 0
     gpu.upload(ed)
     _, a, sa = gpu.render(0, 4, precision=rtamd.F64, seed=8)
-    assert sa["scene_in_lds"] == 12 and sa["paths_redone"] > 1000, sa
+    assert sa["scene_in_lds"] == 12 and sa["rays_retraced"] > 1000, sa
     monkeypatch.setenv("RTAMD_F64_LIST", "1")
     gpu.upload(ed)
     _, b, sb = gpu.render(0, 4, precision=rtamd.F64, seed=8)
     monkeypatch.delenv("RTAMD_F64_LIST")
     gpu.upload(hs)
-    assert sb["scene_in_lds"] in (7, 8) and sb["paths_redone"] == 0
+    assert sb["scene_in_lds"] in (7, 8) and sb["rays_retraced"] == 0
     assert sa["rays"] == sb["rays"], (sa["rays"], sb["rays"])
     assert (np.abs(a - b) / (np.abs(b) + 1e-3)).max() < 1e-12
     # and the overlap shows ONE of the two materials (which one is the reference's rule), not a mixture of them from pixel to pixel

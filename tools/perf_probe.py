@@ -23,6 +23,6 @@ for rep in range(int(os.environ.get("PROBE_REPS", "3"))):
     t0 = time.time()
     st = ctx.render_accum(None, 0, spp, precision=prec, samples_per_pass=spass, pipeline=pipe)
     dt = time.time() - t0
-print("pipe %d " % pipe + "%s %s spp=%d pass=%d: wall %.1f ms, lib %.1f ms, bounce kernels %.1f ms (%d launches), gen %.1f ms, passes %d, rays %.3fG, %d paths redone -> %.2f Grays/s (kernel-only %.2f)"
+print("pipe %d " % pipe + "%s %s spp=%d pass=%d: wall %.1f ms, lib %.1f ms, bounce kernels %.1f ms (%d launches), gen %.1f ms, passes %d, rays %.3fG, %d rays traced again at ties -> %.2f Grays/s (kernel-only %.2f)"
       % (scene, {rtamd.F32: "f32", rtamd.F64: "f64"}.get(prec, "f64 own tree"), spp, spass, dt * 1e3, st["seconds"] * 1e3, st["bounce_kernel_ms"], st["bounce_kernel_launches"], st["gen_kernel_ms"],
-         st["passes"], st["rays"] / 1e9, st["paths_redone"], st["rays"] / st["seconds"] / 1e9, st["rays"] / (st["bounce_kernel_ms"] * 1e-3) / 1e9))
+         st["passes"], st["rays"] / 1e9, st["rays_retraced"], st["rays"] / st["seconds"] / 1e9, st["rays"] / (st["bounce_kernel_ms"] * 1e-3) / 1e9))
