@@ -52,6 +52,16 @@ struct alignas(128) WideNode {
   uint32_t child[4];
   uint32_t pad[4];
 };
+#ifdef RT_WIDE_Q8
+// Measurement build: the single-precision images keep a node in 64 bytes - the corner and cell size of a 256-step grid per axis
+// and the children's boxes as 8-bit grid coordinates (lower bounds rounded down, upper bounds up), four to a word.
+struct alignas(64) WideNodeQ {
+  float org[3], cell[3];
+  uint32_t qlo[3], qhi[3];  // byte c of word a: child c, axis a
+  uint32_t child[4];
+};
+static_assert(sizeof(WideNodeQ) == 64, "quantised wide node size");
+#endif
 // Entries of a lane's stack of the wide walk, one 32-bit child each.  The host refuses the walk (and falls back to the threaded
 // list) for a tree whose worst case needs more: three pushes per level of the path from the root.  36 entries are 144 bytes a
 // lane, which lets four waves per SIMD share a compute unit's 160 KiB of LDS - the walk lives on memory latency, and its speed

@@ -507,7 +507,29 @@ template <class R> struct WideLane {
   // one step on the node `cur`
   RT_DEV void box_step(const WideNode* wide, uint32_t* stack, const LaneBoxTest<R>& box, const Ray<R>& ray, R t_min, R closest) {
     const uint32_t lane = threadIdx.x & 63u;
+#ifdef RT_WIDE_Q8
+    WideNode nd;
+    if constexpr (sizeof(R) == sizeof(float)) {
+      const WideNodeQ q = reinterpret_cast<const WideNodeQ*>(wide)[cur];
+      const float inf_ = Lim<float>::inf();
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        nd.child[c] = q.child[c];
+        const bool used = q.child[c] != kWideNone;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const float lo = q.org[a] + (float)((q.qlo[a] >> (8 * c)) & 255u) * q.cell[a];
+          const float hi = q.org[a] + (float)((q.qhi[a] >> (8 * c)) & 255u) * q.cell[a];
+          nd.lo[a][c] = used ? lo : inf_;
+          nd.hi[a][c] = used ? hi : inf_;
+        }
+      }
+    } else {
+      nd = wide[cur];
+    }
+#else
     const WideNode nd = wide[cur];
+#endif
     float key[4];
     uint32_t ch[4];
 #pragma unroll

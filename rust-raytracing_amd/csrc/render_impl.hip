@@ -70,6 +70,39 @@ template <class R> void layout_sections(BlobLayout& lay) {
   lay.total_bytes = off;
 }
 
+#ifdef RT_WIDE_Q8
+// Measurement build: WideNode -> WideNodeQ, conservatively (a decoded box contains the original).
+__global__ void k_quantize_wide(const WideNode* src, uint32_t n, WideNodeQ* dst) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const WideNode nd = src[k];
+  WideNodeQ q;
+  for (int a = 0; a < 3; ++a) {
+    float lo = INFINITY, hi = -INFINITY;
+    for (int ch = 0; ch < 4; ++ch)
+      if (nd.child[ch] != kWideNone) { lo = fminf(lo, nd.lo[a][ch]); hi = fmaxf(hi, nd.hi[a][ch]); }
+    if (!(hi >= lo)) { lo = 0.0f; hi = 0.0f; }
+    float cell = (hi - lo) / 254.0f;
+    if (!(cell > 0.0f)) cell = 1e-30f;
+    q.org[a] = lo; q.cell[a] = cell;
+    q.qlo[a] = 0u; q.qhi[a] = 0u;
+    for (int ch = 0; ch < 4; ++ch) {
+      uint32_t ql = 0u, qh = 255u;
+      if (nd.child[ch] != kWideNone) {
+        ql = (uint32_t)fminf(fmaxf(floorf((nd.lo[a][ch] - lo) / cell), 0.0f), 255.0f);
+        while (ql > 0u && lo + (float)ql * cell > nd.lo[a][ch]) --ql;
+        qh = (uint32_t)fminf(fmaxf(ceilf((nd.hi[a][ch] - lo) / cell), 0.0f), 255.0f);
+        while (qh < 255u && lo + (float)qh * cell < nd.hi[a][ch]) ++qh;
+      }
+      q.qlo[a] |= ql << (8 * ch);
+      q.qhi[a] |= qh << (8 * ch);
+    }
+  }
+  for (int ch = 0; ch < 4; ++ch) q.child[ch] = nd.child[ch];
+  dst[k] = q;
+}
+#endif
+
 template <class R>
 int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink>& links, int root_link, const std::vector<int>& sub_root_of_object,
                 int preset, SceneImage<R>& im, const std::vector<WideTmp>* wide, const std::vector<uint32_t>* pre, bool exact,
@@ -290,6 +323,16 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
   HIP_TRY(hipMemcpy(im.d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
   if (wide_on_device) HIP_TRY(hipMemcpy(im.d_blob + lay.wide_off, device_wide, (size_t)lay.n_wide * sizeof(WideNode), hipMemcpyDeviceToDevice));
   im.device_built_tree = wide_on_device;
+#ifdef RT_WIDE_Q8
+  if (lay.n_wide && single) {  // the 64-byte nodes, packed, over the first half of the section
+    WideNodeQ* tmp = nullptr;
+    HIP_TRY(hipMalloc((void**)&tmp, (size_t)lay.n_wide * sizeof(WideNodeQ)));
+    hipLaunchKernelGGL(k_quantize_wide, dim3((lay.n_wide + 255u) / 256u), dim3(256), 0, c->stream, reinterpret_cast<const WideNode*>(im.d_blob + lay.wide_off), lay.n_wide, tmp);
+    HIP_TRY(hipMemcpyAsync(im.d_blob + lay.wide_off, tmp, (size_t)lay.n_wide * sizeof(WideNodeQ), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(tmp));
+  }
+#endif
   if (preset == PRESET_ALL_LDS && lay.total_bytes > kLdsAllMax) preset = PRESET_ALL_TOP;  // the f64 image is larger than the f32 one
   if (preset == PRESET_BALLS_LDS && lay.total_bytes > kLdsAllMax) preset = PRESET_BALLS_TOP;
   if (preset == PRESET_FLATALL_LDS && lay.total_bytes > kLdsAllMax) preset = PRESET_FLATALL_TOP;
