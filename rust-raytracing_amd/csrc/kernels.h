@@ -421,6 +421,9 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? (sizeof(R) == 8 ? RT_NESTED
         sum = V3<R>((R)0, (R)0, (R)0);
       }
     } else {
+      // (the pixel's row and column are used within this turn only; the single-precision noise kernel, capped at 128 registers,
+      // is told so - nothing carried from turn to turn - while the other instantiations measure better left alone)
+      if constexpr (C::has(F_NOISE) && sizeof(R) == sizeof(float)) { px_row = 0u; px_col = 0u; }
       feeder.template refill<false, FIXED_GRAB>(sc, fp, total_paths, path_cursor, st, bounce, active, px_row, px_col);
     }
     RT_STAMP(0);
@@ -612,6 +615,10 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
           to_scatter = true;
         }
       }
+      // used within this restart only; cleared so that nothing is carried across the walk (two registers the single-precision kernels
+      // with every feature were spilling: final-scene f32 8.3 -> 8.65 Grays/s.  The flat-walk kernel is better off without: cleared
+      // there, cornell-box f64 goes from 54.1 to 50.6)
+      px_row = 0u; px_col = 0u;
       feeder.template refill<false, FIXED_GRAB>(sc, fp, total_paths, path_cursor, st, bounce, active, px_row, px_col);
       if (i < 0 && active) {  // one Philox pass: scatter draw of the continuing lanes, pixel jitter of the new ones
         const PrimedStream rng(Stream(fp.seed, st.pixel, st.sample, bounce, to_scatter ? STAGE_SCATTER : STAGE_CAMERA), to_scatter ? resume : 0u, kBlocksPerRestart);
