@@ -539,8 +539,10 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
   // on the caller's tree fills the record at every accepted candidate, as the reference does (a hit that writes no (u, v) must find
   // the ones an earlier candidate left), unless the launcher knows that nothing reads such a leftover (DEFER_LIST).
   constexpr bool DEFER = C::template defer_records<R>() || (DEFER_LIST && C::costly_records());
-  // presets with boxes, wrappers or media have the longer leaf code and wait for more lanes before they run it (final-scene +2-3 %)
-  constexpr uint32_t leaf_threshold = C::costly_records() ? kLeafLanesCostly : kLeafLanes;
+  // presets with boxes, wrappers or media have the longer leaf code and wait for more lanes before they run it (final-scene +2-3 %);
+  // not so the double-precision four-wide walk, whose node steps cost as much as its leaves (final-scene f64 at 8 / 12 / 16 / 24 /
+  // 32 lanes: 4.29 / 4.38 / 4.38 / 4.30 / 4.18 Grays/s)
+  constexpr uint32_t leaf_threshold = C::costly_records() && !(WIDE && sizeof(R) == sizeof(double)) ? kLeafLanesCostly : kLeafLanes;
   int best_leaf = -1, best_side = -1;
   R closest = Lim<R>::inf();
   bool any = false;
@@ -577,6 +579,10 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
     const unsigned long long idle = __ballot(i < 0);
     if ((uint32_t)__popcll(idle) >= (WIDE ? kRestartLanesWide : kRestartLanes) || idle == ~0ull) {
       bool to_scatter = false;
+      // Kernels that build the record after the walk use it inside this block only: a lane whose scatter draw goes on at the next
+      // restart keeps (closest, leaf, side) - or its tie flag - and has the record built again then.  Cleared here, the record's
+      // two dozen registers are not carried across the walk.
+      if constexpr (DEFER) rec = Rec<R>();
       if constexpr (EXACT) {
         // A walk that met a tie - two different leaves at exactly the same distance - answers nothing by itself: which of the two
         // the reference reports hangs on the order of its walk and on its boxes (src/bvh.rs:108-119, src/aabb.rs:40).  The lane
@@ -587,16 +593,13 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
           Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
           rec = Rec<R>();
           any = traverse_lane<R, C, 0>(sv, sc.root_link, st.ray, (R)0.001, Lim<R>::inf(), rec, media, st.org, 0u, nullptr);
-          best_leaf = -1;
-          ++retraced;
+          if (resume == 0u) ++retraced;  // (a lane in the middle of its scatter draw comes by again: the same ray)
         }
-        if (i < 0) tie = false;
       }
       if constexpr (DEFER) {
-        if (i < 0 && active && best_leaf >= 0) {  // the walk has ended on a hit: its record, once
+        if (i < 0 && active && best_leaf >= 0 && !tie) {  // the walk has ended on a hit: its record
           finalize_hit<R, C>(sv, st.ray, closest, best_leaf, best_side, rec);
           any = true;
-          best_leaf = -1;
         }
       }
       if (i < 0 && active) {
@@ -648,6 +651,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
         closest = Lim<R>::inf();
         any = false;
         best_leaf = -1;
+        tie = false;
         rec = Rec<R>();  // a fresh HitRecord per world.hit call (src/render.rs:157)
         if constexpr (WIDE) {  // objects as large as the scene, kept outside the tree: all starting lanes test them together
           Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
