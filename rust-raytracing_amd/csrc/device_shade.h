@@ -45,15 +45,18 @@ template <class R> RT_DEV R perlin_turbulence(const DPerlin<R>& pn, V3<R> pt, in
 RT_DEV uint32_t sat_u32(float x) { return !(x > 0.0f) ? 0u : (x >= 4294967295.0f ? 4294967295u : (uint32_t)x); }
 RT_DEV uint32_t sat_u32(double x) { return !(x > 0.0) ? 0u : (x >= 4294967295.0 ? 4294967295u : (uint32_t)x); }
 
-// Texture::value.  LEVEL 0 may be a checker whose two sub-textures are evaluated at LEVEL 1.
-template <class R, class C, int LEVEL> RT_DEV V3<R> texture_value(const SceneView<R, C>& sv, int tex, R u, R v, V3<R> p) {
+// Texture::value.  LEVEL 0 may be a checker whose two sub-textures are evaluated at LEVEL 1.  Only an image reads (u, v): a
+// sphere's are worked out here (get_sphere_uv, an arc cosine and an arc tangent), for the lanes that look a texel up, and not
+// for every sphere a wave has hit.
+template <class R, class C, int LEVEL> RT_DEV V3<R> texture_value(const SceneView<R, C>& sv, int tex, const Rec<R>& rec) {
   const DTexture<R> t = sv.textures[tex];
+  const V3<R> p = rec.p;
   switch (t.tag) {
     case TEX_SOLID: return V3<R>(t.color[0], t.color[1], t.color[2]);  // src/texture.rs:29-33
     case TEX_CHECKER: {                                               // src/texture.rs:54-63
       if constexpr (LEVEL == 0 && C::has(F_CHECKER)) {
         R sines = rt_sin((R)10 * p.x) * rt_sin((R)10 * p.y) * rt_sin((R)10 * p.z);
-        return texture_value<R, C, 1>(sv, sines < (R)0 ? t.odd : t.even, u, v, p);
+        return texture_value<R, C, 1>(sv, sines < (R)0 ? t.odd : t.even, rec);
       } else {
         return V3<R>((R)0, (R)0, (R)0);
       }
@@ -65,8 +68,10 @@ template <class R, class C, int LEVEL> RT_DEV V3<R> texture_value(const SceneVie
     case TEX_IMAGE: if constexpr (C::has(F_IMAGE)) {  // src/texture.rs:128-159
       if (t.image < 0) return V3<R>((R)0, (R)1, (R)1);
       const DImage im = sv.images[t.image];
-      R uc = rt_min(rt_max(u, (R)0), (R)1);
-      R vc = (R)1 - rt_min(rt_max(v, (R)0), (R)1);
+      Rec<R> final_rec = rec;
+      final_rec.finish_uv();
+      R uc = rt_min(rt_max(final_rec.u, (R)0), (R)1);
+      R vc = (R)1 - rt_min(rt_max(final_rec.v, (R)0), (R)1);
       uint32_t i = sat_u32(uc * (R)im.width);
       uint32_t j = sat_u32(vc * (R)im.height);
       if (i >= (uint32_t)im.width) i = (uint32_t)im.width - 1u;
@@ -93,7 +98,7 @@ template <class R> RT_DEV R schlick_reflectance(R cosine, R ref_idx) {  // src/m
 // material then carries in `albedo` (scenes without any other kind of texture never look at the texture records).
 template <class R, class C> RT_DEV V3<R> material_color(const SceneView<R, C>& sv, const DMaterial<R>& m, const Rec<R>& rec) {
   if (!C::has(F_CHECKER | F_NOISE | F_IMAGE) || 0 > m.texture) return V3<R>(m.albedo[0], m.albedo[1], m.albedo[2]);
-  return texture_value<R, C, 0>(sv, m.texture, rec.u, rec.v, rec.p);
+  return texture_value<R, C, 0>(sv, m.texture, rec);
 }
 
 // material.emitted + material.scatter for a final hit record (src/render.rs:162-176).
@@ -101,7 +106,6 @@ template <class R, class C> RT_DEV V3<R> material_color(const SceneView<R, C>& s
 template <class R, class C, class S>
 RT_DEV bool shade_hit(const SceneView<R, C>& sv, const Ray<R>& ray_in, Rec<R>& rec, const S& rng, V3<R>& emitted, V3<R>& attenuation,
                       Ray<R>& scattered) {
-  if constexpr (C::has(F_UV)) rec.finish_uv();
   const DMaterial<R> m = sv.materials[rec.mat];
   emitted = V3<R>((R)0, (R)0, (R)0);
   scattered.o = rec.p;

@@ -516,6 +516,19 @@ constexpr int kTurnsPerCheck = RT_TURNS;
 #endif
 constexpr int kWideStepsPerTurn = RT_WIDE_STEPS;  // node steps of the four-wide walk between two looks at the waiting leaves
 
+// The stepwise kernel's stamps.  -DRT_STAMPS: [0] restart blocks, [1] node steps, [2] leaf steps and the lane counts in [3]..[7].
+// -DRT_STAMPS -DRT_STAMPS_RESTART: cycles only, the restart block cut up - [0] rays traced again at a tie, [1] records, [2] ended
+// paths (background, lights, depth), [3] refill, [4] Philox + scatter + primary rays, [5] walk set-up and the objects kept outside
+// the tree, [6] node steps, [7] leaf steps.
+#ifdef RT_STAMPS_RESTART
+#define SW_STAMP(k) RT_STAMP((k) + 5)
+#define SW_RSTAMP(k) RT_STAMP(k)
+#define SW_COUNT(k, n) do {} while (0)
+#else
+#define SW_STAMP(k) RT_STAMP(k)
+#define SW_RSTAMP(k) do {} while (0)
+#define SW_COUNT(k, n) RT_STAMP_COUNT(k, n)
+#endif
 template <class R, class C, bool FIXED_GRAB, bool DEFER_LIST = false>
 __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == WALK_LANE_WIDE && sizeof(R) == 4) ? RT_WIDE_WAVES_F32 : C::has(F_NESTED) ? RT_NESTED_WAVES : (C::has(F_NOISE) ? (sizeof(R) == 8 ? (C::has(F_EXACT) ? RT_STEP_WAVES_EXACT_F64 : RT_STEP_WAVES_FULL_F64) : RT_STEP_WAVES_FULL) : RT_STEP_WAVES)) void k_paths_stepwise(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
                                                         unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
@@ -596,12 +609,14 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
           if (resume == 0u) ++retraced;  // (a lane in the middle of its scatter draw comes by again: the same ray)
         }
       }
+      SW_RSTAMP(0);
       if constexpr (DEFER) {
         if (i < 0 && active && best_leaf >= 0 && !tie) {  // the walk has ended on a hit: its record
           finalize_hit<R, C>(sv, st.ray, closest, best_leaf, best_side, rec);
           any = true;
         }
       }
+      SW_RSTAMP(1);
       if (i < 0 && active) {
         if (!any) {
           add_radiance(accum, st.pixel, st.thr * background_color<R, C>(sc.background, st.ray.d));
@@ -621,8 +636,10 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
       // used within this restart only; cleared so that nothing is carried across the walk (two registers the single-precision kernels
       // with every feature were spilling: final-scene f32 8.3 -> 8.65 Grays/s.  The flat-walk kernel is better off without: cleared
       // there, cornell-box f64 goes from 54.1 to 50.6)
+      SW_RSTAMP(2);
       px_row = 0u; px_col = 0u;
       feeder.template refill<false, FIXED_GRAB>(sc, fp, total_paths, path_cursor, st, bounce, active, px_row, px_col);
+      SW_RSTAMP(3);
       if (i < 0 && active) {  // one Philox pass: scatter draw of the continuing lanes, pixel jitter of the new ones
         const PrimedStream rng(Stream(fp.seed, st.pixel, st.sample, bounce, to_scatter ? STAGE_SCATTER : STAGE_CAMERA), to_scatter ? resume : 0u, kBlocksPerRestart);
         if (to_scatter) {
@@ -641,9 +658,10 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
           st.ray = primary_ray_at<R, C::relaxed()>(sv.camera(), fp.width, fp.height, px_row, px_col, rng);
         }
       }
+      SW_RSTAMP(4);
       const bool start = i < 0 && active && resume == 0u;
       n_rays += (unsigned long long)__popcll(__ballot(start));
-      RT_STAMP_COUNT(7, __popcll(__ballot(i < 0)));
+      SW_COUNT(7, __popcll(__ballot(i < 0)));
       if (start) {
         box = LaneBoxTest<R>(st.ray);
         if constexpr (WIDE) { wl.start(); i = 0; }
@@ -660,7 +678,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
       }
       if (__ballot(i >= 0 || resume != 0u) == 0ull) break;  // no walk in progress, no draw unfinished, no path left to start
     }
-    RT_STAMP(0);
+    SW_STAMP(0);
     if constexpr (WIDE) {
 #pragma unroll 1
       for (int turn = 0; turn < kTurnsPerCheck; ++turn) {
@@ -668,22 +686,22 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
         for (int k = 0; k < kWideStepsPerTurn; ++k) {
           const bool at_box = wl.at_box();
           if (__ballot(at_box) == 0ull) break;
-          RT_STAMP_COUNT(3, __popcll(__ballot(at_box)));
-          RT_STAMP_COUNT(4, 1);
+          SW_COUNT(3, __popcll(__ballot(at_box)));
+          SW_COUNT(4, 1);
           if (at_box) wl.box_step(sv.wide, sv.stack, box, st.ray, (R)0.001, closest);
         }
-        RT_STAMP(1);
+        SW_STAMP(1);
         const bool at_leaf = wl.at_leaf();
         const unsigned long long leaf_lanes = __ballot(at_leaf);
         if ((uint32_t)__popcll(leaf_lanes) < leaf_threshold && __ballot(wl.at_box()) != 0ull) continue;
-        RT_STAMP_COUNT(5, __popcll(leaf_lanes));
-        RT_STAMP_COUNT(6, 1);
+        SW_COUNT(5, __popcll(leaf_lanes));
+        SW_COUNT(6, 1);
         if (at_leaf) {
           Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
           step_leaf(wl.cur, media);
           wl.pop(sv.stack);
         }
-        RT_STAMP(2);
+        SW_STAMP(2);
       }
       if (wl.idle()) i = LINK_END;
       continue;
@@ -694,8 +712,8 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
       for (int k = 0; k < kBoxStepsPerTurn; ++k) {
         const bool at_box = i >= 0 && !(lk.hit & LEAF_FLAG);
         if (__ballot(at_box) == 0ull) break;
-        RT_STAMP_COUNT(3, __popcll(__ballot(at_box)));
-        RT_STAMP_COUNT(4, 1);
+        SW_COUNT(3, __popcll(__ballot(at_box)));
+        SW_COUNT(4, 1);
         if (at_box) {
           i = box.hit(lk, st.ray, (R)0.001, closest) ? (int)lk.hit : lk.miss;
           if (i >= 0) lk = sv.link(i);
@@ -703,19 +721,19 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == W
       }
       // Leaves are tested when enough lanes stand on one (or no lane has a box to test): the leaf code is several times longer than
       // a box step, and run for the one or two lanes that happen to have arrived it would cost as much as for a full wave.
-      RT_STAMP(1);
+      SW_STAMP(1);
       const bool at_leaf = i >= 0 && (lk.hit & LEAF_FLAG);
       const unsigned long long leaf_lanes = __ballot(at_leaf);
       if ((uint32_t)__popcll(leaf_lanes) < leaf_threshold && __ballot(i >= 0 && !(lk.hit & LEAF_FLAG)) != 0ull) continue;
-      RT_STAMP_COUNT(5, __popcll(leaf_lanes));
-      RT_STAMP_COUNT(6, 1);
+      SW_COUNT(5, __popcll(leaf_lanes));
+      SW_COUNT(6, 1);
       if (at_leaf) {
         Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
         step_leaf(lk.hit, media);
         i = lk.miss;
         if (i >= 0) lk = sv.link(i);
       }
-      RT_STAMP(2);
+      SW_STAMP(2);
     }
   }
   RT_STAMP_FLUSH(ray_count);
