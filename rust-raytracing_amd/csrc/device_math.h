@@ -38,6 +38,26 @@ RT_DEV float min_plain(float a, float b) { return __builtin_fminf(a, b); }
 RT_DEV float max_plain(float a, float b) { return __builtin_fmaxf(a, b); }
 RT_DEV float rt_sin(float x) { return sinf(x); }
 RT_DEV double rt_sin(double x) { return sin(x); }
+// sin(x) < 0 without the sine, for the checker texture (src/texture.rs:54-63), which looks at nothing but the sign of a product of
+// three sines.  sin(t) = (-1)^k sin(r) with k = nearest integer to t / pi and r = t - k pi in [-pi/2, pi/2], where sin has the sign
+// of r.  Double precision: pi is taken in three pieces of 33 bits, so that k * piece is exact for |k| < 2^20 and r comes out with an
+// absolute error near 1e-25 - no double below 1e6 in magnitude lies that close to a multiple of pi, so the sign is the sign of the
+// true sine; larger or non-finite arguments report `big` and the caller evaluates the library's sine.  `zero`: sin(t) == 0 (t == 0).
+RT_DEV bool sine_negative(double t, bool& zero, bool& big) {
+  big = big | !(__builtin_fabs(t) < 1.0e6);
+  zero = zero | (t == 0.0);
+  const double k = __builtin_rint(t * 0.318309886183790671538);
+  double r = t - k * (2.0 * 1.57079632673412561417e+00);
+  r = r - k * (2.0 * 6.07710050630396597660e-11);
+  r = r - k * (2.0 * 2.02226624871116645580e-21);
+  return (r < 0.0) != (((int)k & 1) != 0);
+}
+// Single precision (tolerance mode): the parity of floor(t / pi); within a float's rounding of a multiple of pi either answer is as
+// good as the position it is asked for.
+RT_DEV bool sine_negative(float t, bool& zero, bool&) {
+  zero = zero | (t == 0.0f);
+  return ((int)__builtin_floorf(t * 0.318309886f) & 1) != 0;
+}
 RT_DEV float rt_log(float x) { return logf(x); }
 RT_DEV double rt_log(double x) { return log(x); }
 RT_DEV float rt_acos(float x) { return acosf(x); }

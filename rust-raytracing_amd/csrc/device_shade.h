@@ -55,8 +55,20 @@ template <class R, class C, int LEVEL> RT_DEV V3<R> texture_value(const SceneVie
     case TEX_SOLID: return V3<R>(t.color[0], t.color[1], t.color[2]);  // src/texture.rs:29-33
     case TEX_CHECKER: {                                               // src/texture.rs:54-63
       if constexpr (LEVEL == 0 && C::has(F_CHECKER)) {
-        R sines = rt_sin((R)10 * p.x) * rt_sin((R)10 * p.y) * rt_sin((R)10 * p.z);
-        return texture_value<R, C, 1>(sv, sines < (R)0 ? t.odd : t.even, rec);
+        // sines < 0: an odd number of negative factors and none of them zero (sine_negative); arguments too large for that -
+        // coordinates beyond 10^5 - take the product of the library's sines
+        bool zero = false, big = false;
+        bool negative = sine_negative((R)10 * p.x, zero, big) != sine_negative((R)10 * p.y, zero, big);
+        negative = (negative != sine_negative((R)10 * p.z, zero, big)) && !zero;
+        if (__ballot(big) != 0ull) {
+          if (big) {
+            R sines = (R)1;
+#pragma unroll 1
+            for (int k = 0; k < 3; ++k) sines = sines * rt_sin((R)10 * (k == 0 ? p.x : k == 1 ? p.y : p.z));
+            negative = sines < (R)0;
+          }
+        }
+        return texture_value<R, C, 1>(sv, negative ? t.odd : t.even, rec);
       } else {
         return V3<R>((R)0, (R)0, (R)0);
       }

@@ -529,8 +529,19 @@ constexpr int kWideStepsPerTurn = RT_WIDE_STEPS;  // node steps of the four-wide
 #define SW_RSTAMP(k) do {} while (0)
 #define SW_COUNT(k, n) RT_STAMP_COUNT(k, n)
 #endif
+#ifndef RT_STEP_WAVES_BALLS_F64
+#define RT_STEP_WAVES_BALLS_F64 4  // the double-precision four-wide walk of sphere scenes: 127 to 143 registers as the compiler pleases; held at 128
+#endif
+// Waves per SIMD asked of the compiler for an instantiation of the stepwise kernel (a cap on its registers).
+template <class R, class C> constexpr int step_waves() {
+  if (RT_WIDE_WAVES_F32 && C::walk == WALK_LANE_WIDE && sizeof(R) == 4) return RT_WIDE_WAVES_F32;
+  if (C::has(F_NESTED)) return RT_NESTED_WAVES;
+  if (C::has(F_NOISE)) return sizeof(R) == 8 ? (C::has(F_EXACT) ? RT_STEP_WAVES_EXACT_F64 : RT_STEP_WAVES_FULL_F64) : RT_STEP_WAVES_FULL;
+  if (C::walk == WALK_LANE_WIDE && sizeof(R) == 8) return RT_STEP_WAVES_BALLS_F64;
+  return RT_STEP_WAVES;
+}
 template <class R, class C, bool FIXED_GRAB, bool DEFER_LIST = false>
-__global__ __launch_bounds__(RT_STEP_THREADS, (RT_WIDE_WAVES_F32 && C::walk == WALK_LANE_WIDE && sizeof(R) == 4) ? RT_WIDE_WAVES_F32 : C::has(F_NESTED) ? RT_NESTED_WAVES : (C::has(F_NOISE) ? (sizeof(R) == 8 ? (C::has(F_EXACT) ? RT_STEP_WAVES_EXACT_F64 : RT_STEP_WAVES_FULL_F64) : RT_STEP_WAVES_FULL) : RT_STEP_WAVES)) void k_paths_stepwise(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
+__global__ __launch_bounds__(RT_STEP_THREADS, (step_waves<R, C>())) void k_paths_stepwise(DeviceScene<R> sc, FrameParams fp, unsigned long long total_paths,
                                                         unsigned long long* path_cursor, unsigned long long* ray_count, R* accum) {
   extern __shared__ __align__(16) uint8_t lds[];
   const SceneView<R, C> sv = make_view<R, C>(sc, lds);

@@ -419,3 +419,41 @@ def test_progressive_render_ends_at_the_one_shot_image(gpu, rtamd):
         # earlier pictures are noisier estimates of the whole frame (lit pixels in every quarter of it), not parts of it
         first = images[0].reshape(2, 48, 2, 48, 3).max(axis=(1, 3, 4))
         assert (first > 0).all(), first
+
+
+def test_checker_far_from_the_origin(gpu, rtamd, oracle):
+    """The checker texture looks at the sign of sin(10x) sin(10y) sin(10z) only (src/texture.rs:54-63).  The device decides it
+    from the arguments' position between multiples of pi while they stay below 10^6 and from the product of the library's sines
+    beyond; both must pick the colour the oracle's sines pick.  Two emissive checker spheres far down the view direction - hit
+    points with coordinates near 5*10^4 on the nearer one, above 10^5 on the farther - rendered at depth 1, where a pixel's radiance
+    is the texture's colour at the hit point: compared with the oracle's texture at the point the device reports, pixel by pixel."""
+    from custom_scene import EditedScene
+    base = rtamd.Scene("two-spheres", width=160, spp=1)
+    os_ = oracle.OracleScene("two-spheres", width=160, spp=1)
+    cam = base.camera()
+    origin, view = cam[0:3], -cam[18:21]
+    ed = EditedScene(rtamd, base)
+    near_c, far_c = origin + 5e4 * view, origin + 6e5 * view
+    ed.shapes["p"][0][0:4] = [*near_c, 1e4]
+    ed.shapes["p"][1][0:4] = [*far_c, 4e5]
+    ed.nodes["bmin"][0] = np.minimum(near_c - 1e4, far_c - 4e5)
+    ed.nodes["bmax"][0] = np.maximum(near_c + 1e4, far_c + 4e5)
+    ed.materials["tag"][0] = 3  # a diffuse light whose emission is the checker
+    gpu.upload(ed)
+    n = ed.width * ed.height
+    pixel, sample = np.arange(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)
+    rays = gpu.camera_rays(pixel, sample, seed=4)
+    rays["tmin"], rays["tmax"] = 0.001, np.inf
+    hits = gpu.trace_batch(rays, precision=rtamd.F64, seed=4)
+    on = hits["hit"] != 0
+    assert on.mean() > 0.95
+    p = hits["p"][on]
+    big = (np.abs(10 * p) >= 1e6).any(axis=1)
+    assert 0.1 < big.mean() < 0.9, big.mean()  # both ways of deciding the sign are exercised
+    want = np.array([os_.texture_value(0, 0.0, 0.0, q) for q in p])
+    assert len(np.unique(want, axis=0)) == 2
+    _, acc, st = gpu.render(0, 1, precision=rtamd.F64, seed=4, depth=1)
+    got = acc.reshape(-1, 3)[on]
+    wrong = (np.abs(got - want) > 1e-12).any(axis=1)
+    assert wrong.sum() == 0, (int(wrong.sum()), int(on.sum()), p[wrong][:4])
+    gpu.upload(base)
