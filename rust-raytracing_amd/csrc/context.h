@@ -42,6 +42,7 @@ constexpr uint32_t kCounterWords = (kMaxDepth + 2) * kSegments * 11;  // per bou
 
 template <class R> struct SceneImage {
   uint8_t* d_blob = nullptr;
+  double* d_exact_boxes = nullptr;  // DeviceScene::exact_boxes, when the image has them
   DeviceScene<R> dev{};
   int preset = PRESET_ALL_TOP;
   KernelTable<R> table{};

@@ -156,6 +156,11 @@ template <class R> struct DeviceScene {
   uint32_t n_pre;      // four-wide walk: leaves tested ahead of the walk (objects as large as the scene), leaf words in `pre`
   uint32_t pre[4];
   uint32_t defer_ok;   // no texture of the scene reads the (u, v) a moving sphere or a medium inherits from an earlier candidate
+  // Double precision, scenes with planar shapes whose tree boxes are not all floats: the boxes of the links as the caller gave them
+  // (six doubles per link: min xyz, max xyz; global memory), else null.  Whether the second of two exactly coincident surfaces is
+  // still visited hangs on an exact comparison in the reference's box test (src/aabb.rs:40); a box the stored float form lets a
+  // ray into is tested once more in this form.
+  const double* exact_boxes;
   DCamera<R> camera;
   DBackground<R> background;
 };
@@ -324,6 +329,7 @@ template <class R, class C> struct SceneView {
   const WideNode* wide;               // WALK_LANE_WIDE: the four-wide tree (global memory)
   uint32_t* stack;                    // ... and the stacks of the lane's wave in LDS: child words, [entry][lane]
   uint32_t n_pre, pre[4];             // ... and the leaves tested ahead of the walk
+  const double* exact_boxes;          // see DeviceScene::exact_boxes (null in nearly every scene)
 
   RT_DEV DCamera<R> camera() const { return camera_of(load_uniform(camera_rec)); }
   RT_DEV static DCamera<R> camera_of(const CameraRecord<R>& r) {
@@ -399,6 +405,7 @@ template <class R, class C> RT_DEV SceneView<R, C> make_view(const DeviceScene<R
   v.n_pre = sc.n_pre;
   for (int k = 0; k < 4; ++k) v.pre[k] = sc.pre[k];
   v.stack = reinterpret_cast<uint32_t*>(lds + (threadIdx.x >> 6) * kWideStackBytesPerWave);
+  v.exact_boxes = sc.exact_boxes;
   v.n_links = sc.lay.n_links;
   v.links = reinterpret_cast<const BoxLink*>(geom + sc.lay.links_off);
   v.shapes = reinterpret_cast<const DShape<R>*>(geom + sc.lay.shapes_off);

@@ -398,9 +398,22 @@ template <> struct LaneBoxTest<double> {
   RT_DEV explicit LaneBoxTest(const Ray<double>& ray) : inv(rcp_refined(ray.d.x), rcp_refined(ray.d.y), rcp_refined(ray.d.z)) {
     plain = __builtin_isfinite(inv.x) & __builtin_isfinite(inv.y) & __builtin_isfinite(inv.z) & (inv.x != 0.0) & (inv.y != 0.0) & (inv.z != 0.0);
   }
-  RT_DEV bool hit(const BoxLink& f, const Ray<double>& ray, double t_min, double t_max) const {
+  // `exact`, `i`: DeviceScene::exact_boxes and the link's index - a box whose float form lets the ray in is tested again as the
+  // caller gave it (scenes that have no such array: one scalar branch)
+  RT_DEV bool hit(const BoxLink& f, const Ray<double>& ray, double t_min, double t_max, const double* exact = nullptr, int i = 0) const {
     DLink<double> b;  // the stored box, widened to double (exact)
     for (int k = 0; k < 3; ++k) { b.bmin[k] = (double)f.bmin[k]; b.bmax[k] = (double)f.bmax[k]; }
+    bool h = test(b, ray, t_min, t_max);
+    if (exact != nullptr) {
+      if (h) {
+        const double* e = exact + 6 * (size_t)i;
+        for (int k = 0; k < 3; ++k) { b.bmin[k] = e[k]; b.bmax[k] = e[3 + k]; }
+        h = test(b, ray, t_min, t_max);
+      }
+    }
+    return h;
+  }
+  RT_DEV bool test(const DLink<double>& b, const Ray<double>& ray, double t_min, double t_max) const {
     if (plain) {
       const double x0 = (b.bmin[0] - ray.o.x) * inv.x, x1 = (b.bmax[0] - ray.o.x) * inv.x;
       const double y0 = (b.bmin[1] - ray.o.y) * inv.y, y1 = (b.bmax[1] - ray.o.y) * inv.y;
@@ -416,7 +429,7 @@ template <> struct LaneBoxTest<float> {
   V3<float> inv;
   RT_DEV explicit LaneBoxTest(const Ray<float>& ray)
       : inv(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z)) {}
-  RT_DEV bool hit(const DLink<float>& b, const Ray<float>& ray, float t_min, float t_max) const {
+  RT_DEV bool hit(const DLink<float>& b, const Ray<float>& ray, float t_min, float t_max, const double* = nullptr, int = 0) const {
     const float x0 = (b.bmin[0] - ray.o.x) * inv.x, x1 = (b.bmax[0] - ray.o.x) * inv.x;
     const float y0 = (b.bmin[1] - ray.o.y) * inv.y, y1 = (b.bmax[1] - ray.o.y) * inv.y;
     const float z0 = (b.bmin[2] - ray.o.z) * inv.z, z1 = (b.bmax[2] - ray.o.z) * inv.z;
@@ -439,7 +452,7 @@ RT_DEV bool traverse_lane(const SceneView<R, C>& sv, int start, const Ray<R>& ra
     // entered by the lanes together instead of once per lane that happens to reach a leaf.
     while (!(lk.hit & LEAF_FLAG)) {
       if (tally) ++tally->boxes;
-      i = box.hit(lk, ray, t_min, closest) ? (int)lk.hit : lk.miss;
+      i = box.hit(lk, ray, t_min, closest, sv.exact_boxes, i) ? (int)lk.hit : lk.miss;
       if (i < 0) break;
       lk = sv.link(i);
     }

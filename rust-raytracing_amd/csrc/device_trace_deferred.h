@@ -572,7 +572,7 @@ RT_DEV bool traverse_lane_deferred(const SceneView<float, C>& sv, int start, con
     DLink<float> lk = sv.link(i);
     while (!(lk.hit & LEAF_FLAG)) {
       if (tally) ++tally->boxes;
-      i = box.hit(lk, ray, t_min, closest) ? (int)lk.hit : lk.miss;
+      i = box.hit(lk, ray, t_min, closest, sv.exact_boxes, i) ? (int)lk.hit : lk.miss;
       if (i < 0) break;
       lk = sv.link(i);
     }
@@ -597,7 +597,7 @@ RT_DEV bool traverse_lane_deferred(const SceneView<float, C>& sv, int start, con
             DLink<float> nl = sv.link(j);
             while (!(nl.hit & LEAF_FLAG)) {
               if (tally) ++tally->boxes;
-              j = lbox.hit(nl, local, lo, hi) ? (int)nl.hit : nl.miss;
+              j = lbox.hit(nl, local, lo, hi, sv.exact_boxes, j) ? (int)nl.hit : nl.miss;
               if (j < 0) break;
               nl = sv.link(j);
             }

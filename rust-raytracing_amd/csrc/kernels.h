@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? (sizeof(R) == 8 ? RT_NESTED
 #define RT_STEP_WAVES_FULL_F64 3  // double precision: final-scene on the library's tree 3.71 / 3.95 / 3.83 Grays/s at 4 / 3 / 2 waves per SIMD, on the caller's tree no difference
 #endif
 #ifndef RT_STEP_WAVES_EXACT_F64
-#define RT_STEP_WAVES_EXACT_F64 2  // the reference's leaf arithmetic on the four-wide walk (six rectangles to a box, wrapped spheres): all 256 registers and no spills, final-scene 4.05 -> 4.2 Grays/s against three waves
+#define RT_STEP_WAVES_EXACT_F64 3  // the reference's leaf arithmetic on the four-wide walk (six rectangles to a box, wrapped spheres) and the list walk for rays that tie: it wants 275 registers; 1 / 2 / 3 / 4 waves (512 / 256 / 168 / 128 registers, 0 / 18 / 97 / 170 of them spilled): final-scene 2.6 / 4.4 / 4.8 / 4.75 Grays/s
 #endif
 #ifndef RT_WIDE_WAVES_F32
 #define RT_WIDE_WAVES_F32 0  // != 0: waves per SIMD asked for the single-precision four-wide kernels (measurement switch; needs RT_WIDE_STACK to match the LDS)
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (step_waves<R, C>())) void k_paths
   // F_EXACT: two different leaves at exactly the same distance - the order of the tests would decide (see traverse_wide)
   constexpr bool EXACT = WIDE && C::has(F_EXACT) && sizeof(R) == sizeof(double);
   bool tie = false;
-  unsigned long long retraced = 0;  // per lane: rays answered a second time by the list walk
+  unsigned long long retraced = 0;  // rays of the wave answered a second time by the list walk (the same in every lane)
   auto step_leaf = [&](uint32_t word, Stream& media) {
     if constexpr (DEFER) {
       RayInv<R> ri(st.ray.d);
@@ -617,8 +617,9 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (step_waves<R, C>())) void k_paths
           Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
           rec = Rec<R>();
           any = traverse_lane<R, C, 0>(sv, sc.root_link, st.ray, (R)0.001, Lim<R>::inf(), rec, media, st.org, 0u, nullptr);
-          if (resume == 0u) ++retraced;  // (a lane in the middle of its scatter draw comes by again: the same ray)
         }
+        // (a lane in the middle of its scatter draw comes by again: the same ray, counted once)
+        retraced += (unsigned long long)__popcll(__ballot(i < 0 && active && tie && resume == 0u));
       }
       SW_RSTAMP(0);
       if constexpr (DEFER) {
@@ -750,7 +751,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (step_waves<R, C>())) void k_paths
   RT_STAMP_FLUSH(ray_count);
   if (lane == 0u && n_rays != 0ull) atomicAdd(ray_count, n_rays);
   if constexpr (EXACT) {
-    if (retraced != 0ull) atomicAdd(ray_count + 1, retraced);
+    if (lane == 0u && retraced != 0ull) atomicAdd(ray_count + 1, retraced);
   }
 }
 

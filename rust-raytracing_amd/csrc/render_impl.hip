@@ -345,6 +345,32 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
   d.n_images = s.n_images;
   d.root_link = root_link;
   d.defer_ok = (reads_leftover_uv(s) || getenv("RTAMD_EAGER_RECORDS")) ? 0u : 1u;
+  // The boxes as the caller gave them, beside their float form, where that form could change an answer: a scene with planar shapes
+  // (two of them can coincide exactly, and which one the reference reports then hangs on `t_max <= t_min` in its box test,
+  // src/aabb.rs:40) whose tree has a box coordinate that is not a float.  Every scene of the reference has float coordinates there.
+  d.exact_boxes = nullptr;
+  if (!single && !links.empty() && !getenv("RTAMD_NO_EXACT_BOXES")) {
+    bool planar = false;
+    for (int i = 0; i < s.n_shapes && !planar; ++i) planar = s.shapes[i].tag >= RT_SHAPE_RECT_XY && s.shapes[i].tag <= RT_SHAPE_BOX;
+    bool all_floats = true;
+    if (planar)
+      for (size_t i = 0; i < links.size() && all_floats; ++i)
+        if (!(links[i].hit & LEAF_FLAG))
+          for (int k = 0; k < 3; ++k) all_floats = all_floats && (double)(float)links[i].bmin[k] == links[i].bmin[k] && (double)(float)links[i].bmax[k] == links[i].bmax[k];
+    if (planar && !all_floats) {
+      std::vector<double> e(6 * links.size());
+      for (size_t i = 0; i < links.size(); ++i) {
+        const bool inverted = links[i].bmin[0] > links[i].bmax[0] || links[i].bmin[1] > links[i].bmax[1] || links[i].bmin[2] > links[i].bmax[2];
+        for (int k = 0; k < 3; ++k) {  // (an inverted box: the point at +infinity, as in the links)
+          e[6 * i + k] = inverted ? std::numeric_limits<double>::infinity() : links[i].bmin[k];
+          e[6 * i + 3 + k] = inverted ? std::numeric_limits<double>::infinity() : links[i].bmax[k];
+        }
+      }
+      HIP_TRY(hipMalloc((void**)&im.d_exact_boxes, e.size() * sizeof(double)));
+      HIP_TRY(hipMemcpy(im.d_exact_boxes, e.data(), e.size() * sizeof(double), hipMemcpyHostToDevice));
+      d.exact_boxes = im.d_exact_boxes;
+    }
+  }
   d.n_pre = 0;
   if (lay.n_wide && pre)
     for (uint32_t word : *pre) {

@@ -49,6 +49,7 @@ namespace {
 
 template <class R> void free_image(SceneImage<R>& im) {
   if (im.d_blob) (void)hipFree(im.d_blob);
+  if (im.d_exact_boxes) (void)hipFree(im.d_exact_boxes);
   im = SceneImage<R>{};
 }
 
