@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? (sizeof(R) == 8 ? RT_NESTED
 #define RT_STEP_WAVES_FULL_F64 3  // double precision: final-scene on the library's tree 3.71 / 3.95 / 3.83 Grays/s at 4 / 3 / 2 waves per SIMD, on the caller's tree no difference
 #endif
 #ifndef RT_STEP_WAVES_EXACT_F64
-#define RT_STEP_WAVES_EXACT_F64 3  // the reference's leaf arithmetic on the four-wide walk (six rectangles to a box, wrapped spheres) and the list walk for rays that tie: it wants 275 registers; 1 / 2 / 3 / 4 waves (512 / 256 / 168 / 128 registers, 0 / 18 / 97 / 170 of them spilled): final-scene 2.6 / 4.4 / 4.8 / 4.75 Grays/s
+#define RT_STEP_WAVES_EXACT_F64 3  // the reference's leaf arithmetic on the four-wide walk (six rectangles to a box, wrapped spheres) and the list walk for rays that tie; 2 / 3 / 4 waves (256 / 168 / 128 registers; 74 put aside at three, all of them in the restart block): final-scene 4.5 / 5.2 / 5.1 Grays/s
 #endif
 #ifndef RT_WIDE_WAVES_F32
 #define RT_WIDE_WAVES_F32 0  // != 0: waves per SIMD asked for the single-precision four-wide kernels (measurement switch; needs RT_WIDE_STACK to match the LDS)
@@ -613,15 +613,36 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (step_waves<R, C>())) void k_paths
         // traces the ray once more, by the list walk of the caller's tree in the reference's order, while the other lanes of the
         // wave wait: a few thousand rays of a frame's half billion (final-scene: rays that slip between two ground blocks), a
         // fraction of a percent of the waves' time.  Word 1 of the counter block counts them.
-        if (i < 0 && active && tie) {
+        const bool redo = i < 0 && active && tie;
+        // (a lane in the middle of its scatter draw comes by again with its answer, no longer with the tie)
+        retraced += (unsigned long long)__popcll(__ballot(redo));
+        if (redo) {
+          // the same leaf tests as the four-wide walk's, over the threaded list: (closest, leaf, side) of the reference's answer,
+          // from which the record is built below like any other
           Stream media(fp.seed, st.pixel, st.sample, bounce, STAGE_MEDIA);
-          rec = Rec<R>();
-          any = traverse_lane<R, C, 0>(sv, sc.root_link, st.ray, (R)0.001, Lim<R>::inf(), rec, media, st.org, 0u, nullptr);
+          RayInv<R> ri(st.ray.d);
+          ri.inv = box.inv;
+          closest = Lim<R>::inf();
+          best_leaf = -1; best_side = -1;
+          int j = sc.root_link;
+          while (j >= 0) {
+            BoxLink e = sv.link(j);
+            while (!(e.hit & LEAF_FLAG)) {
+              j = box.hit(e, st.ray, (R)0.001, closest, sv.exact_boxes, j) ? (int)e.hit : e.miss;
+              if (j < 0) break;
+              e = sv.link(j);
+            }
+            if (j < 0) break;
+            R t;
+            int side;
+            if (leaf_t<R, C>(sv, e.hit, st.ray, ri, (R)0.001, closest, media, st.org, t, side, visit_bit(e.hit, 0))) {
+              closest = t; best_leaf = (int)(e.hit & LEAF_INDEX_MASK); best_side = side;
+            }
+            j = e.miss;
+          }
+          tie = false;
         }
-        // (a lane in the middle of its scatter draw comes by again: the same ray, counted once)
-        retraced += (unsigned long long)__popcll(__ballot(i < 0 && active && tie && resume == 0u));
       }
-      SW_RSTAMP(0);
       if constexpr (DEFER) {
         if (i < 0 && active && best_leaf >= 0 && !tie) {  // the walk has ended on a hit: its record
           finalize_hit<R, C>(sv, st.ray, closest, best_leaf, best_side, rec);
