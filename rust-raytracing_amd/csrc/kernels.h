@@ -379,10 +379,7 @@ __global__ __launch_bounds__(256, C::has(F_NESTED) ? (sizeof(R) == 8 ? RT_NESTED
       if (!hit) {
         term = st.thr * background_color<R, C>(sc.background, st.ray.d);
       } else if (sv.materials[rec.mat].tag == MAT_LIGHT) {  // emits, never scatters (src/material.rs:148-167)
-        V3<R> emitted, attenuation;
-        Ray<R> scattered;
-        shade_hit<R, C>(sv, st.ray, rec, Stream(fp.seed, st.pixel, st.sample, bounce, STAGE_SCATTER), emitted, attenuation, scattered);
-        term = st.thr * emitted;
+        term = st.thr * material_color<R, C>(sv, sv.materials[rec.mat], rec);
       } else if (bounce + 1u >= fp.max_depth) {  // ray_color(depth == 0) contributes nothing (src/render.rs:151-153)
       } else {
         to_scatter = true;
@@ -655,10 +652,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (step_waves<R, C>())) void k_paths
           add_radiance(accum, st.pixel, st.thr * background_color<R, C>(sc.background, st.ray.d));
           active = false;
         } else if (sv.materials[rec.mat].tag == MAT_LIGHT) {  // emits, never scatters (src/material.rs:148-167)
-          V3<R> emitted, attenuation;
-          Ray<R> scattered;
-          shade_hit<R, C>(sv, st.ray, rec, Stream(fp.seed, st.pixel, st.sample, bounce, STAGE_SCATTER), emitted, attenuation, scattered);
-          add_radiance(accum, st.pixel, st.thr * emitted);
+          add_radiance(accum, st.pixel, st.thr * material_color<R, C>(sv, sv.materials[rec.mat], rec));
           active = false;
         } else if (bounce + 1u >= fp.max_depth) {  // ray_color(depth == 0) contributes nothing (src/render.rs:151-153)
           active = false;
