@@ -78,6 +78,21 @@ typedef struct rth_render_config {
 } rth_render_config;
 int rth_render_and_save(const rth_render_config* cfg, rt_stats* stats_out);
 
+/* One item of the stream that ThreadedRenderer::check_progress drains: type Pixel = (u32, u32, Rgb<u8>) (src/render.rs:39). */
+typedef struct rth_pixel {
+  uint32_t x, y; /* y counted from the top row, as the reference sends it (src/render.rs:239) */
+  uint8_t rgb[3];
+  uint8_t pad;
+} rth_pixel;
+/* A frame as that stream delivers it, for a host that sits where the GUI's check_progress loop sits (src/render.rs:84-108):
+ * items first .. first + max_items of the frame's width * height pixels, in the order the reference's workers send theirs - the
+ * row blocks of divide_into_ranges(height, workers) (src/render.rs:218,247-271) one after the other (the reference's run
+ * concurrently, so its interleaving is not defined), inside a block from the row with the largest j down (src/render.rs:224: the
+ * block's rows counted from the bottom of the image, in reverse), left to right inside a row.  `rgb8` is a frame as rt_render or
+ * rt_progress_step writes it (row 0 on top); after a progress step every pixel has changed, so a GUI drains the frame again.
+ * Returns the number of items written to `out` (0 past the end or on a bad argument). */
+size_t rth_pixel_stream(const uint8_t* rgb8, uint32_t width, uint32_t height, uint32_t workers, size_t first, size_t max_items, rth_pixel* out);
+
 const char* rth_last_error(void);
 
 #ifdef __cplusplus

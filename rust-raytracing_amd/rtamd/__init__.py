@@ -34,7 +34,7 @@ ABI_SYMBOLS = ["rt_create", "rt_destroy", "rt_upload_scene", "rt_render_accum", 
                "rt_progress_begin", "rt_progress_step", "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_reduce_accum",
                "rt_trace_batch", "rt_camera_rays", "rt_sample_radiance", "rt_sample_path", "rt_last_error", "rt_version"]
 HOST_ABI_SYMBOLS = ["rth_scene_create", "rth_scene_destroy", "rth_scene_desc", "rth_scene_config", "rth_scene_from_name",
-                    "rth_scene_name", "rth_save_image", "rth_load_ppm", "rth_free", "rth_render_and_save", "rth_last_error"]
+                    "rth_scene_name", "rth_save_image", "rth_load_ppm", "rth_free", "rth_render_and_save", "rth_pixel_stream", "rth_last_error"]
 
 
 class RtError(RuntimeError):
@@ -391,6 +391,22 @@ def comm_unique_id():
     buf = (C.c_char * 128)()
     _check(L.rt_comm_unique_id(C.byref(buf)))
     return bytes(buf.raw)
+
+
+PIXEL_DTYPE = np.dtype([("x", "<u4"), ("y", "<u4"), ("rgb", "u1", 3), ("pad", "u1")])  # = rth_pixel
+
+
+def pixel_stream(rgb, workers, first=0, max_items=None):
+    """rth_pixel_stream: the (x, y, rgb) items ThreadedRenderer::check_progress would drain for this frame (src/render.rs:39,84-108)."""
+    _, H = load_libraries()
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w = rgb.shape[:2]
+    n = w * h if max_items is None else max_items
+    out = np.zeros(n, dtype=PIXEL_DTYPE)
+    H.rth_pixel_stream.restype = C.c_size_t
+    H.rth_pixel_stream.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, C.c_size_t, C.c_void_p]
+    got = H.rth_pixel_stream(_p(rgb), w, h, workers, first, n, _p(out))
+    return out[:got]
 
 
 def save_image(path, rgb):

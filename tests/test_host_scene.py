@@ -277,7 +277,7 @@ def test_binding_layouts_match_the_header(rtamd, tmp_path):
     added to the header without its mirror, or a pad forgotten, shows up here and not as a garbled render."""
     ct = {"rt_render_params": rtamd.RenderParams, "rt_stats": rtamd.Stats, "rth_scene_opts": rtamd.SceneOpts, "rth_render_config": rtamd.RenderConfig}
     dt = {"rt_bvh_node": rtamd.NODE_DTYPE, "rt_object": rtamd.OBJECT_DTYPE, "rt_shape": rtamd.SHAPE_DTYPE, "rt_material": rtamd.MATERIAL_DTYPE,
-          "rt_texture": rtamd.TEXTURE_DTYPE, "rt_ray": rtamd.RAY_DTYPE, "rt_hit": rtamd.HIT_DTYPE}
+          "rt_texture": rtamd.TEXTURE_DTYPE, "rt_ray": rtamd.RAY_DTYPE, "rt_hit": rtamd.HIT_DTYPE, "rth_pixel": rtamd.PIXEL_DTYPE}
     sizes = {"rt_scene_desc": ctypes.sizeof(rtamd.SceneDesc), "rt_camera": 24 * 8, "rt_background": 8 + 48, "rt_perlin": 256 * 24 + 3 * 1024,
              "rt_image": 16, "rt_comm_id": 128}
     lines = []
@@ -313,3 +313,32 @@ def test_binding_layouts_match_the_header(rtamd, tmp_path):
                 assert dt[cname].fields[fname][1] == int(off), (cname, fname)
         else:
             assert sizes[cname] == int(size), (cname, sizes[cname], size)
+
+
+def test_pixel_stream_is_the_reference_workers_order(rtamd):
+    """rth_pixel_stream: every pixel of a frame exactly once, as (x, y from the top, rgb), in the order the reference's workers
+    send theirs (src/render.rs:218-241): row blocks of divide_into_ranges (the oracle's restatement of it), each block from its
+    last row (largest j, counted from the bottom) to its first, left to right; drained in pieces like check_progress drains."""
+    import oracle_lib
+    oracle_lib.build()
+    rng = np.random.default_rng(6)
+    for w, h, workers in ((7, 5, 3), (16, 9, 15), (4, 3, 8), (5, 1, 1)):
+        rgb = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        want = []
+        for lo, hi in oracle_lib.divide_into_ranges(h, workers):
+            for j in range(int(hi) - 1, int(lo) - 1, -1):
+                y = h - 1 - j
+                want += [(i, y, tuple(rgb[y, i])) for i in range(w)]
+        assert len(want) == w * h and len({(x, y) for x, y, _ in want}) == w * h
+        whole = rtamd.pixel_stream(rgb, workers)
+        assert [(int(p["x"]), int(p["y"]), tuple(p["rgb"])) for p in whole] == want
+        pieces, first = [], 0
+        while True:
+            part = rtamd.pixel_stream(rgb, workers, first=first, max_items=6)
+            if len(part) == 0:
+                break
+            pieces += [(int(p["x"]), int(p["y"]), tuple(p["rgb"])) for p in part]
+            first += len(part)
+        assert pieces == want
+    assert len(rtamd.pixel_stream(np.zeros((2, 2, 3), np.uint8), 0)) == 0  # no workers: nothing (the reference clamps to >= 1)
+
