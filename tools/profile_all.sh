@@ -1,5 +1,5 @@
 #!/bin/bash
-# The round's profiles in one go: tools/profile_all.sh <part>; part 1 = headline + final-scene, part 2 = the million-sphere frame under its two cameras.
+# The profile set kept under profiles/ in one go: tools/profile_all.sh <part>; part 1 = headline + final-scene, part 2 = the million-sphere frame under its two cameras.
 # Each is tools/profile_round.sh (kernel trace of the bench command + counter passes); digest afterwards with tools/profile_digest.py.
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"

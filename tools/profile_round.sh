@@ -1,5 +1,5 @@
 #!/bin/bash
-# Profiles of the headline bench command for one round, written under gpurun_out/profile_<tag>/:
+# Profiles of the bench command under one tag, written under gpurun_out/profile_<tag>/:
 #   trace/   rocprofv3 --kernel-trace --stats of `python3 bench.py` (the driver's command, CPU baseline included)
 #   pmc_<precision>_*/   counter passes (one rocprofv3 run each, counters only) of
 #            `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --precision <precision>`, for f64 and f32
