@@ -92,3 +92,15 @@ def test_shared_face_at_a_non_float_coordinate(gpu, rtamd, oracle, monkeypatch):
     got = gpu.trace_batch(rays, precision=rtamd.F64)
     assert (got["obj"][inside_a] == 2).all() and (got["obj"] != want[:, 0]).any()
     gpu.upload(ed)  # (the context's scene for whoever comes next is restored by their own upload)
+
+
+def test_path_kernels_agree_on_the_scene(gpu, rtamd):
+    """The same scene rendered by the persistent pipeline (whose per-lane walk steps through the list entry by entry and has a box
+    test of its own) and by the queue pipeline (one walk per ray): identical ray counts and sums in double precision, with the
+    caller's boxes in use in both."""
+    ed, _, _ = _scene(rtamd)
+    gpu.upload(ed)
+    _, a, sa = gpu.render(0, 16, precision=rtamd.F64, seed=3, pipeline=rtamd.PIPELINE_PERSISTENT)
+    _, b, sb = gpu.render(0, 16, precision=rtamd.F64, seed=3, pipeline=rtamd.PIPELINE_FUSED)
+    assert sa["rays"] == sb["rays"] and sa["rays"] > sa["camera_rays"]  # some paths bounce off the boxes
+    assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max())
