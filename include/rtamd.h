@@ -209,6 +209,7 @@ typedef struct rt_stats {
 #define RT_VARIANT_STEPWISE 4u         /* k_paths_stepwise (per-lane tree walks) instead of k_paths_persistent */
 #define RT_VARIANT_DEFERRED_RECORDS 8u /* double precision on the caller's tree: hit record built once, after the walk */
 #define RT_VARIANT_DEVICE_TREE 16u     /* the tree the kernel walked was built on the GPU at upload (scenes of 100 000 objects and more) */
+#define RT_VARIANT_NARROW_BOXES 32u    /* double precision on the library's tree: child boxes tested in single precision, widened so that no box is missed */
 
 typedef struct rt_context rt_context;
 

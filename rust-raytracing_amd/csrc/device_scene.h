@@ -161,6 +161,7 @@ template <class R> struct DeviceScene {
   // still visited hangs on an exact comparison in the reference's box test (src/aabb.rs:40); a box the stored float form lets a
   // ray into is tested once more in this form.
   const double* exact_boxes;
+  uint32_t narrow_ok;  // four-wide tree: every box coordinate within +-2^40, so the double-precision walk may test the boxes in single precision (wide_keys)
   DCamera<R> camera;
   DBackground<R> background;
 };
@@ -330,6 +331,7 @@ template <class R, class C> struct SceneView {
   uint32_t* stack;                    // ... and the stacks of the lane's wave in LDS: child words, [entry][lane]
   uint32_t n_pre, pre[4];             // ... and the leaves tested ahead of the walk
   const double* exact_boxes;          // see DeviceScene::exact_boxes (null in nearly every scene)
+  bool narrow_ok;                     // see DeviceScene::narrow_ok
 
   RT_DEV DCamera<R> camera() const { return camera_of(load_uniform(camera_rec)); }
   RT_DEV static DCamera<R> camera_of(const CameraRecord<R>& r) {
@@ -406,6 +408,7 @@ template <class R, class C> RT_DEV SceneView<R, C> make_view(const DeviceScene<R
   for (int k = 0; k < 4; ++k) v.pre[k] = sc.pre[k];
   v.stack = reinterpret_cast<uint32_t*>(lds + (threadIdx.x >> 6) * kWideStackBytesPerWave);
   v.exact_boxes = sc.exact_boxes;
+  v.narrow_ok = sc.narrow_ok != 0u;
   v.n_links = sc.lay.n_links;
   v.links = reinterpret_cast<const BoxLink*>(geom + sc.lay.links_off);
   v.shapes = reinterpret_cast<const DShape<R>*>(geom + sc.lay.shapes_off);

@@ -395,8 +395,16 @@ template <class R> struct LaneBoxTest;
 template <> struct LaneBoxTest<double> {
   V3<double> inv;
   bool plain;
-  RT_DEV explicit LaneBoxTest(const Ray<double>& ray) : inv(rcp_refined(ray.d.x), rcp_refined(ray.d.y), rcp_refined(ray.d.z)) {
+  // The four-wide walk may test its child boxes in single precision (wide_keys below): the ray's origin and reciprocals are of
+  // ordinary size (2^-40 .. 2^40: no product of the test can overflow or vanish) and the scene allows it.
+  bool narrow;
+  RT_DEV explicit LaneBoxTest(const Ray<double>& ray, bool allow_narrow = false)
+      : inv(rcp_refined(ray.d.x), rcp_refined(ray.d.y), rcp_refined(ray.d.z)) {
     plain = __builtin_isfinite(inv.x) & __builtin_isfinite(inv.y) & __builtin_isfinite(inv.z) & (inv.x != 0.0) & (inv.y != 0.0) & (inv.z != 0.0);
+    const double big = 0x1p40, small = 0x1p-40;
+    const double ax = __builtin_fabs(inv.x), ay = __builtin_fabs(inv.y), az = __builtin_fabs(inv.z);
+    narrow = allow_narrow & plain & (ax <= big) & (ay <= big) & (az <= big) & (ax >= small) & (ay >= small) & (az >= small) &
+             (__builtin_fabs(ray.o.x) <= big) & (__builtin_fabs(ray.o.y) <= big) & (__builtin_fabs(ray.o.z) <= big);
   }
   // `exact`, `i`: DeviceScene::exact_boxes and the link's index - a box whose float form lets the ray in is tested again as the
   // caller gave it (scenes that have no such array: one scalar branch)
@@ -427,7 +435,7 @@ template <> struct LaneBoxTest<double> {
 };
 template <> struct LaneBoxTest<float> {
   V3<float> inv;
-  RT_DEV explicit LaneBoxTest(const Ray<float>& ray)
+  RT_DEV explicit LaneBoxTest(const Ray<float>& ray, bool = false)
       : inv(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z)) {}
   RT_DEV bool hit(const DLink<float>& b, const Ray<float>& ray, float t_min, float t_max, const double* = nullptr, int = 0) const {
     const float x0 = (b.bmin[0] - ray.o.x) * inv.x, x1 = (b.bmax[0] - ray.o.x) * inv.x;
@@ -506,6 +514,44 @@ RT_DEV float wide_child_key(const LaneBoxTest<double>& box, const WideNode& nd, 
   return box.hit(b, ray, t_min, t_max) ? 0.0f : Lim<float>::inf();
 }
 
+// The four child keys of a node.  Single precision: child by child.
+RT_DEV void wide_keys(const LaneBoxTest<float>& box, const WideNode& nd, const Ray<float>& ray, float t_min, float t_max, float key[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) key[c] = wide_child_key(box, nd, c, ray, t_min, t_max);
+}
+// Double precision.  The boxes of the library's tree decide nothing but which leaves get tested, so their test may err on the
+// side of entering a box - and then it can run in single precision, where an operation issues at half the cost of a double one
+// and the node's floats need no conversion: three quarters of a node step's instructions were this test.  With u = 2^-24, the
+// origin rounded to a float is off by at most u |o|, the reciprocal by u |1/d|, and the difference and the product round once
+// each: a plane distance t computed this way differs from (c - o) / d by at most 3.01 u |t| + 1.01 u |o / d|.  Each axis' near
+// distance is lowered and its far distance raised by e = 4 u |o / d|, and after the intervals of the three axes, t_min and the
+// closest hit so far (rounded to a float: off by u) are combined, the lower end is lowered and the upper end raised by 4 u of
+// themselves once more: whenever the double-precision test enters the box, so does this one.  An unused slot (a box at
+// +infinity) ends in a NaN on one side and fails the comparison.  A ray whose numbers are not of ordinary size (`narrow`)
+// takes the double-precision test.
+RT_DEV void wide_keys(const LaneBoxTest<double>& box, const WideNode& nd, const Ray<double>& ray, double t_min, double t_max, float key[4]) {
+  if (box.narrow) {
+    const float ox = (float)ray.o.x, oy = (float)ray.o.y, oz = (float)ray.o.z;
+    const float ix = (float)box.inv.x, iy = (float)box.inv.y, iz = (float)box.inv.z;
+    const float ex = __builtin_fabsf(ox * ix) * 0x1p-22f, ey = __builtin_fabsf(oy * iy) * 0x1p-22f, ez = __builtin_fabsf(oz * iz) * 0x1p-22f;
+    const float lo = (float)t_min, hi = (float)t_max;
+    const float inf = Lim<float>::inf();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float x0 = (nd.lo[0][c] - ox) * ix, x1 = (nd.hi[0][c] - ox) * ix;
+      const float y0 = (nd.lo[1][c] - oy) * iy, y1 = (nd.hi[1][c] - oy) * iy;
+      const float z0 = (nd.lo[2][c] - oz) * iz, z1 = (nd.hi[2][c] - oz) * iz;
+      const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1) - ex, __builtin_fminf(y0, y1) - ey), __builtin_fmaxf(__builtin_fminf(z0, z1) - ez, lo));
+      const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1) + ex, __builtin_fmaxf(y0, y1) + ey), __builtin_fminf(__builtin_fmaxf(z0, z1) + ez, hi));
+      const float tn_low = __builtin_fmaf(-0x1p-22f, __builtin_fabsf(tn), tn), tf_high = __builtin_fmaf(0x1p-22f, __builtin_fabsf(tf), tf);
+      key[c] = tn_low < tf_high ? tn : inf;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) key[c] = wide_child_key(box, nd, c, ray, t_min, t_max);
+  }
+}
+
 template <class R> struct WideLane {
   uint32_t cur = kWideNone;  // node index, leaf word (LEAF_FLAG), or kWideNone: no walk in progress
   uint32_t sp = 0;
@@ -545,8 +591,9 @@ template <class R> struct WideLane {
 #endif
     float key[4];
     uint32_t ch[4];
+    wide_keys(box, nd, ray, t_min, closest, key);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { key[c] = wide_child_key(box, nd, c, ray, t_min, closest); ch[c] = nd.child[c]; }
+    for (int c = 0; c < 4; ++c) ch[c] = nd.child[c];
     auto order = [&](int a, int b) {
       const bool s = key[b] < key[a];
       const float ka = s ? key[b] : key[a], kb = s ? key[a] : key[b];

@@ -704,7 +704,7 @@ template <class R, class C>
 RT_DEV bool traverse_wide(const SceneView<R, C>& sv, const Ray<R>& ray, R t_min, R t_max, Rec<R>& rec, Stream& media, Origin org, Visits* tally,
                           bool* tie = nullptr) {
   constexpr bool DEFER = C::template defer_records<R>();
-  const LaneBoxTest<R> box(ray);
+  const LaneBoxTest<R> box(ray, sv.narrow_ok);
   WideLane<R> w;
   w.start();
   R closest = t_max;

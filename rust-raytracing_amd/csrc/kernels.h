@@ -690,7 +690,7 @@ __global__ __launch_bounds__(RT_STEP_THREADS, (step_waves<R, C>())) void k_paths
       n_rays += (unsigned long long)__popcll(__ballot(start));
       SW_COUNT(7, __popcll(__ballot(i < 0)));
       if (start) {
-        box = LaneBoxTest<R>(st.ray);
+        box = LaneBoxTest<R>(st.ray, WIDE && sv.narrow_ok);
         if constexpr (WIDE) { wl.start(); i = 0; }
         else { i = sc.root_link; lk = sv.link(i); }
         closest = Lim<R>::inf();

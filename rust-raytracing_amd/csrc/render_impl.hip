@@ -348,6 +348,18 @@ int build_image(rt_context* c, const rt_scene_desc& s, const std::vector<TmpLink
   // The boxes as the caller gave them, beside their float form, where that form could change an answer: a scene with planar shapes
   // (two of them can coincide exactly, and which one the reference reports then hangs on `t_max <= t_min` in its box test,
   // src/aabb.rs:40) whose tree has a box coordinate that is not a float.  Every scene of the reference has float coordinates there.
+  // The double-precision four-wide walk tests child boxes in single precision when no product of that test can overflow: the
+  // root's child boxes contain every other box of the tree.
+  d.narrow_ok = 0u;
+  if (!single && lay.n_wide && !getenv("RTAMD_NO_NARROW_BOXES")) {
+    WideNode root;
+    HIP_TRY(hipMemcpy(&root, im.d_blob + lay.wide_off, sizeof(root), hipMemcpyDeviceToHost));
+    bool ok = true;
+    for (int ch = 0; ch < 4; ++ch)
+      if (root.child[ch] != kWideNone)
+        for (int k = 0; k < 3; ++k) ok = ok && std::fabs(root.lo[k][ch]) <= 0x1p40f && std::fabs(root.hi[k][ch]) <= 0x1p40f;
+    d.narrow_ok = ok ? 1u : 0u;
+  }
   d.exact_boxes = nullptr;
   if (!single && !links.empty() && !getenv("RTAMD_NO_EXACT_BOXES")) {
     bool planar = false;
@@ -515,7 +527,7 @@ template <class R> int render_accum_impl(rt_context* c, const rt_render_params& 
       stats->passes = 1;
       stats->lds_bytes = im.lds_bytes;
       stats->scene_in_lds = (uint32_t)im.preset;
-      stats->kernel_variant = variant | (im.device_built_tree ? RT_VARIANT_DEVICE_TREE : 0u);
+      stats->kernel_variant = variant | (im.device_built_tree ? RT_VARIANT_DEVICE_TREE : 0u) | (im.dev.narrow_ok ? RT_VARIANT_NARROW_BOXES : 0u);
       stats->rays_retraced = retraced;
     }
     return RT_OK;

@@ -22,7 +22,7 @@ F64_OWN_TREE = F64 | 0x400  # double arithmetic on the tree the library builds f
 TRACE_AS_RENDERED = 0x100  # rt_trace_batch: records built by the render kernels' own configuration
 TRACE_VISITS = 0x200       # ... and u, v = box entries / leaves tested by the walk
 PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_SORTED, PIPELINE_PERSISTENT = 0, 1, 2, 3
-VARIANT_FIXED_GRAB, VARIANT_CHUNKED, VARIANT_STEPWISE, VARIANT_DEFERRED_RECORDS, VARIANT_DEVICE_TREE = 1, 2, 4, 8, 16  # Stats.kernel_variant bits
+VARIANT_FIXED_GRAB, VARIANT_CHUNKED, VARIANT_STEPWISE, VARIANT_DEFERRED_RECORDS, VARIANT_DEVICE_TREE, VARIANT_NARROW_BOXES = 1, 2, 4, 8, 16, 32  # Stats.kernel_variant bits
 
 SCENES = {
     "random": 0, "two-spheres": 1, "two-perlin-spheres": 2, "earth": 3, "simple-light": 4,

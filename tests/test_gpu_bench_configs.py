@@ -47,7 +47,7 @@ def test_fixed_grab_kernels_match_the_oracle(gpu, rtamd, oracle, earth_rgb, name
     _, got32, st32 = gpu.render(0, spp, precision=rtamd.F32, seed=77)
     own = gpu.render(0, spp, precision=rtamd.F64_OWN_TREE, seed=77) if st["scene_in_lds"] >= 3 else None
     monkeypatch.delenv("RTAMD_FIXED_GRAB")
-    assert st["kernel_variant"] == (rtamd.VARIANT_FIXED_GRAB | bits), st["kernel_variant"]
+    assert st["kernel_variant"] & ~rtamd.VARIANT_NARROW_BOXES == (rtamd.VARIANT_FIXED_GRAB | bits), st["kernel_variant"]  # (the box-test flag says nothing about the instantiation)
     assert st32["kernel_variant"] & rtamd.VARIANT_FIXED_GRAB
     allow = CHAOTIC.get(name, 0.0)
     assert abs(int(st["rays"]) - int(cnt["rays"])) <= allow * cnt["rays"], (st["rays"], cnt["rays"])

@@ -498,3 +498,30 @@ def test_medium_over_a_nested_tree_f32_matches_f64(gpu, rtamd, earth_rgb):
     both = same & fog
     t_err = np.abs(a["t"][both] - b["t"][both]) * np.linalg.norm(rays["d"][both], axis=1) / 600.0
     assert np.quantile(t_err, 0.999) < 1e-5, (np.quantile(t_err, 0.999), t_err.max())
+
+
+@pytest.mark.parametrize("name,kw", [("random", {}), ("final-scene", {}), ("mega-spheres", {"mega_grid": 100, "width": 160, "spp": 2})])
+def test_single_precision_node_test_changes_no_answer(gpu, rtamd, oracle, earth_rgb, name, kw, monkeypatch):
+    """Double precision on the library's four-wide tree tests a node's child boxes in single precision, widened so that no box
+    the double-precision test enters is passed by (tests/test_narrow_box_test.py holds the arithmetic to that).  A box decides
+    only which leaves get tested, so hits and frames must be those of the double-precision box test (RTAMD_NO_NARROW_BOXES) bit
+    for bit - and the other tests hold this image to the oracle."""
+    hs, _ = make_pair(rtamd, oracle, name, earth=earth_rgb, **kw)
+    rng = np.random.default_rng(99)
+    lo, hi = SCENE_BOXES.get(name, ((-60, 0.05, -60), (60, 3, 60)))
+    rays = random_rays(rng, 200_000, lo, hi)
+    gpu.upload(hs)
+    a = gpu.trace_batch(rays, precision=rtamd.F64, seed=5, as_rendered=True)
+    _, fa, sa = gpu.render(0, 2, precision=rtamd.F64, seed=5)
+    monkeypatch.setenv("RTAMD_NO_NARROW_BOXES", "1")
+    gpu.upload(hs)
+    b = gpu.trace_batch(rays, precision=rtamd.F64, seed=5, as_rendered=True)
+    _, fb, sb = gpu.render(0, 2, precision=rtamd.F64, seed=5)
+    monkeypatch.delenv("RTAMD_NO_NARROW_BOXES")
+    gpu.upload(hs)
+    assert sa["kernel_variant"] & rtamd.VARIANT_NARROW_BOXES and not (sb["kernel_variant"] & rtamd.VARIANT_NARROW_BOXES)
+    assert a["hit"].sum() > 10_000
+    for f in ID_FIELDS + ("t", "p", "n"):
+        assert np.array_equal(a[f], b[f]), (name, f)
+    assert sa["rays"] == sb["rays"] and sa["rays_retraced"] == sb["rays_retraced"]
+    assert (np.abs(fa - fb) / (np.abs(fb) + 1e-3)).max() < 1e-12
