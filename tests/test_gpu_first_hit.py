@@ -525,3 +525,45 @@ def test_single_precision_node_test_changes_no_answer(gpu, rtamd, oracle, earth_
         assert np.array_equal(a[f], b[f]), (name, f)
     assert sa["rays"] == sb["rays"] and sa["rays_retraced"] == sb["rays_retraced"]
     assert (np.abs(fa - fb) / (np.abs(fb) + 1e-3)).max() < 1e-12
+
+
+@pytest.mark.parametrize("name", ["random", "final-scene", "cornell-box"])
+def test_first_hit_rays_with_degenerate_directions_f64(gpu, rtamd, oracle, earth_rgb, name):
+    """Rays whose direction has zero components (1 / d infinite: the box tests fall back to the reference's form as written),
+    components far below or above a float's range (the four-wide walk's single-precision box test steps aside for them) and origins
+    ten thousand units outside the scene (farther out the sphere test's own discriminant loses its digits and the comparison with it): the same hits as the oracle, in the plain query and with the kernel configuration of a render."""
+    hs, os_ = make_pair(rtamd, oracle, name, earth=earth_rgb)
+    gpu.upload(hs)
+    rng = np.random.default_rng(4321)
+    lo, hi = SCENE_BOXES[name]
+    rays = random_rays(rng, 60_000, lo, hi)
+    kind = rng.integers(0, 6, rays.size)
+    axis = rng.integers(0, 3, rays.size)
+    other = (axis + 1 + rng.integers(0, 2, rays.size)) % 3
+    rows = np.arange(rays.size)
+    d = rays["d"].copy()
+    d[rows[kind == 0], axis[kind == 0]] = 0.0                       # one component zero
+    d[rows[kind == 1], axis[kind == 1]] = 0.0                       # two components zero: an axis-parallel ray
+    d[rows[kind == 1], other[kind == 1]] = 0.0
+    d[rows[kind == 2], axis[kind == 2]] = -0.0
+    d[rows[kind == 3], axis[kind == 3]] *= 1e-60                    # reciprocal beyond a float
+    d[rows[kind == 4]] *= 1e45                                      # reciprocals below a float's smallest normal
+    rays["d"] = d
+    # origins 10^4 away, aimed back at the scene.  Not in cornell-box: from below, such a ray meets the floor and the underside of a
+    # box standing on it at exactly the same distance; the small-scene walk gives that tie to the later leaf, the reference to the
+    # floor (its walk never looks into the boxes' node, whose box begins exactly there: src/aabb.rs:40) - a place no path of a
+    # render can come from, stated among the limits of the interface.
+    far = (kind == 5) & (name != "cornell-box")
+    centre = (np.array(lo) + np.array(hi)) / 2
+    rays["o"][far] = centre + 1e4 * rays["d"][far] / np.linalg.norm(rays["d"][far], axis=1, keepdims=True)
+    rays["d"][far] = -rays["d"][far]
+    oh = os_.first_hit(rays, seed=99, precision=1)
+    assert (oh["hit"] == 1).mean() > 0.03
+    for as_rendered in (False, True):
+        gh = gpu.trace_batch(rays, precision=rtamd.F64, seed=99, as_rendered=as_rendered)
+        # ids must agree wherever the hit is not a grazing one
+        same = (gh["hit"] == oh["hit"]) & (gh["obj"] == oh["obj"]) & (gh["sub"] == oh["sub"])
+        assert (~same).sum() <= 2e-4 * rays.size, (name, as_rendered, int((~same).sum()), np.unique(kind[~same], return_counts=True))
+        both = same & (oh["hit"] == 1)
+        rel = np.abs(gh["t"][both] - oh["t"][both]) / np.abs(oh["t"][both])
+        assert rel.max() < 1e-9, (name, rel.max())
